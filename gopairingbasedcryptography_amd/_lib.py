@@ -1,0 +1,56 @@
+"""ctypes loader for the C-ABI library (include/gpbc_bn254.h).  No fallback: if the HIP library is
+missing or no gfx950 device can be bound, every compute call raises."""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libgpbc_bn254.so")
+
+EXPORTS = [
+    "gpbc_init", "gpbc_shutdown", "gpbc_last_error", "gpbc_device_count", "gpbc_abi_version",
+    "gpbc_pair_batch", "gpbc_pair_batch_dev", "gpbc_multi_pair", "gpbc_multi_pair_workspace_bytes",
+    "gpbc_multi_pair_dev", "gpbc_pairing_check", "gpbc_miller_loop_dev", "gpbc_final_exp_dev",
+    "gpbc_miller_loop", "gpbc_final_exp",
+    "gpbc_g1_scalar_mul_batch", "gpbc_g1_scalar_mul_batch_dev", "gpbc_g2_scalar_mul_batch",
+    "gpbc_g2_scalar_mul_batch_dev", "gpbc_g1_sum", "gpbc_g2_sum", "gpbc_sum_workspace_bytes",
+    "gpbc_g1_sum_dev", "gpbc_g2_sum_dev",
+    "gpbc_gt_exp_batch", "gpbc_gt_exp_batch_dev", "gpbc_gt_mul_batch", "gpbc_gt_div_batch",
+    "gpbc_gt_inverse_batch", "gpbc_gt_mul_batch_dev", "gpbc_gt_div_batch_dev", "gpbc_gt_inverse_batch_dev",
+    "gpbc_fp_mul_batch",
+]
+
+_lib = None
+
+
+class EngineError(RuntimeError):
+    """Raised when the C ABI returns a negative gpbc_status."""
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EngineError(
+                "HIP extension %s is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 and device tensors /
+        # streams come from it, so load torch first and let the dynamic loader resolve this library's
+        # libamdhip64.so.7 dependency to that already-loaded copy (two runtimes cannot share the GPU).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        lib = ctypes.CDLL(LIB_PATH)
+        lib.gpbc_last_error.restype = ctypes.c_char_p
+        lib.gpbc_multi_pair_workspace_bytes.restype = ctypes.c_size_t
+        lib.gpbc_multi_pair_workspace_bytes.argtypes = [ctypes.c_size_t, ctypes.c_size_t]
+        lib.gpbc_sum_workspace_bytes.restype = ctypes.c_size_t
+        lib.gpbc_sum_workspace_bytes.argtypes = [ctypes.c_size_t, ctypes.c_int]
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc < 0:
+        raise EngineError("gpbc error %d: %s" % (rc, load().gpbc_last_error().decode()))
+    return rc

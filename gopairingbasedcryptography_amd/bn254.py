@@ -1,0 +1,364 @@
+"""Host-side mirror of the gnark-crypto bn254 surface the reference calls, over the C ABI.
+
+Reference call surface (gnark-crypto v0.19.0 `ecc/bn254`, used e.g. at
+signature/bls01_signature/bls_signature.go:45,63,81 and cpabe/bsw07/bsw07_cpabe.go:75,184):
+
+    bn254.Pair(P []G1Affine, Q []G2Affine) (GT, error)            -> pair(P, Q)
+    bn254.PairingCheck(P, Q) (bool, error)                        -> pairing_check(P, Q)
+    (*G1Affine).ScalarMultiplication(a, s) / ...Base(s)           -> g1_scalar_mul(a, s) / g1_scalar_mul_base(s)
+    (*G2Affine).ScalarMultiplication(a, s) / ...Base(s)           -> g2_scalar_mul(a, s) / g2_scalar_mul_base(s)
+    (*GT).Exp / Mul / Div / Inverse                               -> gt_exp / gt_mul / gt_div / gt_inverse
+    bn254.Generators()                                            -> generators()
+
+plus the batched forms the engine adds (pair_batch, multi_pair, pairing_check_batch).  Points and GT
+values are numpy uint8 arrays (host) or torch uint8 CUDA tensors (HBM-resident) holding gnark in-memory
+structs (Montgomery little-endian limbs): G1 64 B, G2 128 B, GT 384 B; scalars 32-byte little-endian.
+Errors follow gnark: length mismatch or empty input to pair/pairing_check raises ValueError("invalid
+inputs sizes").  Everything computes on the GPU; a missing extension or device raises EngineError.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import EngineError  # noqa: F401  (re-export)
+
+G1_BYTES, G2_BYTES, GT_BYTES, SCALAR_BYTES = 64, 128, 384, 32
+R_ORDER = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+# gnark Generators(): g1 = (1, 2), g2 = the standard alt_bn128 twist generator; Montgomery-form bytes.
+_G1_GEN_HEX = (
+    "9d0d8fc58d435dd33d0bc7f528eb780a2c4679786fa36e662fdf079ac1770a0e3a1b1e8b1b87baa67b168eeb51d6f114"
+    "588cf2f0de46ddcc5ebe0f3483ef141c")
+_G2_GEN_HEX = (
+    "2620bc02d1b5838e72017b493519ebdcdf1a81974726b8fb3b5096af4138571940614ca87d73b4afc4d802585add4360"
+    "862fa052fc50e9096b7bea3a83f0fe14f6e96b889dfa9d61789b9ef597d27ffefe7d1b23621a9eff06429eaeeb7efd28"
+    "ee5618c7565b0964bb3c7d3222f957dc76103533be35f9558264fd93e6a0a40d")
+
+_initialised_device = None
+
+
+def init(device=0):
+    """Bind the process to one HIP device (one process per GPU)."""
+    global _initialised_device
+    lib = _lib.load()
+    _lib.check(lib.gpbc_init(ctypes.c_int(device)))
+    _initialised_device = device
+    return device
+
+
+def _ensure_init():
+    if _initialised_device is None:
+        init(0)
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _np(x, width=None):
+    a = np.ascontiguousarray(x, dtype=np.uint8).reshape(-1)
+    if width is not None and a.size % width:
+        raise ValueError("buffer length %d is not a multiple of %d" % (a.size, width))
+    return a
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _sz(n):
+    return ctypes.c_size_t(n)
+
+
+def scalars_to_bytes(scalars):
+    """ints (any sign/size; reduced mod r like fr.Element.BigInt round trips) or a uint8 buffer -> n x 32 LE bytes."""
+    if isinstance(scalars, (bytes, bytearray, np.ndarray)) or _is_torch(scalars):
+        return scalars
+    if isinstance(scalars, int):
+        scalars = [scalars]
+    return np.frombuffer(b"".join((int(s) % R_ORDER).to_bytes(32, "little") for s in scalars), dtype=np.uint8)
+
+
+def generators():
+    """(g1, g2) affine generators as uint8 arrays (gnark: `_, _, g1, g2 := bn254.Generators()`)."""
+    return (np.frombuffer(bytes.fromhex(_G1_GEN_HEX), dtype=np.uint8).copy(),
+            np.frombuffer(bytes.fromhex(_G2_GEN_HEX), dtype=np.uint8).copy())
+
+
+# --------------------------------------------------------------------------------------- torch (HBM-resident) path
+def _torch_stream():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _tptr(t):
+    if t.dtype.__str__() != "torch.uint8" or not t.is_cuda or not t.is_contiguous():
+        raise ValueError("device buffers must be contiguous uint8 CUDA tensors")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _tnew(like, n, width):
+    import torch
+    return torch.empty((n, width), dtype=torch.uint8, device=like.device)
+
+
+# --------------------------------------------------------------------------------------- pairings
+def pair_batch(P, Q, out=None):
+    """n independent pairings: out[i] = Pair([P[i]], [Q[i]])."""
+    _ensure_init()
+    lib = _lib.load()
+    if _is_torch(P):
+        n = P.numel() // G1_BYTES
+        if Q.numel() // G2_BYTES != n or n == 0:
+            raise ValueError("invalid inputs sizes")
+        out = _tnew(P, n, GT_BYTES) if out is None else out
+        _lib.check(lib.gpbc_pair_batch_dev(_tptr(P), _tptr(Q), _sz(n), _tptr(out), _torch_stream()))
+        return out
+    P, Q = _np(P, G1_BYTES), _np(Q, G2_BYTES)
+    n = P.size // G1_BYTES
+    if Q.size // G2_BYTES != n or n == 0:
+        raise ValueError("invalid inputs sizes")
+    out = np.empty((n, GT_BYTES), dtype=np.uint8)
+    _lib.check(lib.gpbc_pair_batch(_ptr(P), _ptr(Q), _sz(n), _ptr(out)))
+    return out
+
+
+def multi_pair(P, Q, seg_off, out=None, workspace=None):
+    """k products of pairings: out[j] = Pair(P[seg_off[j]:seg_off[j+1]], Q[...]) with one final exponentiation each."""
+    _ensure_init()
+    lib = _lib.load()
+    if _is_torch(P):
+        import torch
+        n = P.numel() // G1_BYTES
+        if Q.numel() // G2_BYTES != n:
+            raise ValueError("invalid inputs sizes")
+        if not _is_torch(seg_off):
+            seg_off = torch.as_tensor(np.ascontiguousarray(seg_off, dtype=np.int64), device=P.device)
+        k = seg_off.numel() - 1
+        out = _tnew(P, k, GT_BYTES) if out is None else out
+        wsb = lib.gpbc_multi_pair_workspace_bytes(n, k)
+        if workspace is None:
+            workspace = torch.empty(max(wsb, 1), dtype=torch.uint8, device=P.device)
+        _lib.check(lib.gpbc_multi_pair_dev(_tptr(P), _tptr(Q), ctypes.c_void_p(seg_off.data_ptr()), _sz(n), _sz(k),
+                                           _tptr(out), _tptr(workspace), _sz(workspace.numel()), _torch_stream()))
+        return out
+    P, Q = _np(P, G1_BYTES), _np(Q, G2_BYTES)
+    seg = np.ascontiguousarray(seg_off, dtype=np.uint64)
+    k = seg.size - 1
+    if Q.size // G2_BYTES != P.size // G1_BYTES or k < 1 or int(seg[-1]) != P.size // G1_BYTES:
+        raise ValueError("invalid inputs sizes")
+    out = np.empty((k, GT_BYTES), dtype=np.uint8)
+    _lib.check(lib.gpbc_multi_pair(_ptr(P), _ptr(Q), _ptr(seg), _sz(k), _ptr(out)))
+    return out
+
+
+def pair(P, Q):
+    """bn254.Pair(P, Q): the product of the pairings of all (P[i], Q[i]); one 384-byte GT."""
+    P, Q = _np(P, G1_BYTES), _np(Q, G2_BYTES)
+    n = P.size // G1_BYTES
+    if n == 0 or Q.size // G2_BYTES != n:
+        raise ValueError("invalid inputs sizes")
+    return multi_pair(P, Q, [0, n])[0]
+
+
+def pairing_check_batch(P, Q, seg_off):
+    _ensure_init()
+    lib = _lib.load()
+    P, Q = _np(P, G1_BYTES), _np(Q, G2_BYTES)
+    seg = np.ascontiguousarray(seg_off, dtype=np.uint64)
+    k = seg.size - 1
+    if Q.size // G2_BYTES != P.size // G1_BYTES or k < 1 or int(seg[-1]) != P.size // G1_BYTES:
+        raise ValueError("invalid inputs sizes")
+    ok = np.empty(k, dtype=np.uint8)
+    _lib.check(lib.gpbc_pairing_check(_ptr(P), _ptr(Q), _ptr(seg), _sz(k), _ptr(ok)))
+    return ok.astype(bool)
+
+
+def pairing_check(P, Q):
+    """bn254.PairingCheck(P, Q): product of pairings == 1."""
+    P, Q = _np(P, G1_BYTES), _np(Q, G2_BYTES)
+    n = P.size // G1_BYTES
+    if n == 0 or Q.size // G2_BYTES != n:
+        raise ValueError("invalid inputs sizes")
+    return bool(pairing_check_batch(P, Q, [0, n])[0])
+
+
+def miller_loop(P, Q):
+    _ensure_init()
+    lib = _lib.load()
+    if _is_torch(P):
+        n = P.numel() // G1_BYTES
+        out = _tnew(P, n, GT_BYTES)
+        _lib.check(lib.gpbc_miller_loop_dev(_tptr(P), _tptr(Q), _sz(n), _tptr(out), _torch_stream()))
+        return out
+    P, Q = _np(P, G1_BYTES), _np(Q, G2_BYTES)
+    n = P.size // G1_BYTES
+    out = np.empty((n, GT_BYTES), dtype=np.uint8)
+    _lib.check(lib.gpbc_miller_loop(_ptr(P), _ptr(Q), _sz(n), _ptr(out)))
+    return out
+
+
+def final_exp(F):
+    _ensure_init()
+    lib = _lib.load()
+    if _is_torch(F):
+        n = F.numel() // GT_BYTES
+        out = _tnew(F, n, GT_BYTES)
+        _lib.check(lib.gpbc_final_exp_dev(_tptr(F), _sz(n), _tptr(out), _torch_stream()))
+        return out
+    F = _np(F, GT_BYTES)
+    n = F.size // GT_BYTES
+    out = np.empty((n, GT_BYTES), dtype=np.uint8)
+    _lib.check(lib.gpbc_final_exp(_ptr(F), _sz(n), _ptr(out)))
+    return out
+
+
+# --------------------------------------------------------------------------------------- scalar multiplication
+def _scalar_mul(width, host_fn, dev_fn, bases, scalars, out):
+    _ensure_init()
+    scalars = scalars_to_bytes(scalars)
+    if _is_torch(scalars):
+        n = scalars.numel() // SCALAR_BYTES
+        nbase = bases.numel() // width
+        if nbase not in (1, n):
+            raise ValueError("need one base or one base per scalar")
+        out = _tnew(scalars, n, width) if out is None else out
+        _lib.check(dev_fn(_tptr(bases), _sz(nbase), _tptr(scalars), _sz(n), _tptr(out), _torch_stream()))
+        return out
+    bases, scalars = _np(bases, width), _np(scalars, SCALAR_BYTES)
+    n, nbase = scalars.size // SCALAR_BYTES, bases.size // width
+    if nbase not in (1, n):
+        raise ValueError("need one base or one base per scalar")
+    out = np.empty((n, width), dtype=np.uint8)
+    _lib.check(host_fn(_ptr(bases), _sz(nbase), _ptr(scalars), _sz(n), _ptr(out)))
+    return out
+
+
+def g1_scalar_mul(bases, scalars, out=None):
+    """out[i] = new(G1Affine).ScalarMultiplication(&bases[i], scalars[i]) (one shared base allowed)."""
+    lib = _lib.load()
+    return _scalar_mul(G1_BYTES, lib.gpbc_g1_scalar_mul_batch, lib.gpbc_g1_scalar_mul_batch_dev, bases, scalars, out)
+
+
+def g2_scalar_mul(bases, scalars, out=None):
+    lib = _lib.load()
+    return _scalar_mul(G2_BYTES, lib.gpbc_g2_scalar_mul_batch, lib.gpbc_g2_scalar_mul_batch_dev, bases, scalars, out)
+
+
+def g1_scalar_mul_base(scalars):
+    """ScalarMultiplicationBase: [s]g1."""
+    return g1_scalar_mul(generators()[0], scalars)
+
+
+def g2_scalar_mul_base(scalars):
+    return g2_scalar_mul(generators()[1], scalars)
+
+
+def _sum(width, is_g2, host_fn, dev_fn, pts):
+    _ensure_init()
+    lib = _lib.load()
+    if _is_torch(pts):
+        import torch
+        n = pts.numel() // width
+        out = _tnew(pts, 1, width)
+        wsb = lib.gpbc_sum_workspace_bytes(n, is_g2)
+        ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=pts.device)
+        _lib.check(dev_fn(_tptr(pts), _sz(n), _tptr(out), _tptr(ws), _sz(ws.numel()), _torch_stream()))
+        return out[0]
+    pts = _np(pts, width)
+    out = np.empty(width, dtype=np.uint8)
+    _lib.check(host_fn(_ptr(pts), _sz(pts.size // width), _ptr(out)))
+    return out
+
+
+def g1_sum(pts):
+    """Sum of affine G1 points (chains of G1Affine.Add in the reference)."""
+    lib = _lib.load()
+    return _sum(G1_BYTES, 0, lib.gpbc_g1_sum, lib.gpbc_g1_sum_dev, pts)
+
+
+def g2_sum(pts):
+    lib = _lib.load()
+    return _sum(G2_BYTES, 1, lib.gpbc_g2_sum, lib.gpbc_g2_sum_dev, pts)
+
+
+# --------------------------------------------------------------------------------------- GT
+def gt_exp(x, k, out=None):
+    """out[i] = new(GT).Exp(x[i], k[i]); Python ints may be negative (inverse, as gnark)."""
+    _ensure_init()
+    lib = _lib.load()
+    if isinstance(k, int):
+        k = [k]
+    if isinstance(k, (list, tuple)) and any(int(s) < 0 for s in k):
+        neg = np.array([int(s) < 0 for s in k])
+        xs = _np(x, GT_BYTES).reshape(-1, GT_BYTES).copy()
+        xs[neg] = gt_inverse(xs[neg])
+        x = xs
+        k = np.frombuffer(b"".join(abs(int(s)).to_bytes(32, "little") for s in k), dtype=np.uint8)
+    elif isinstance(k, (list, tuple)):
+        k = np.frombuffer(b"".join(int(s).to_bytes(32, "little") for s in k), dtype=np.uint8)
+    if _is_torch(x):
+        n = x.numel() // GT_BYTES
+        out = _tnew(x, n, GT_BYTES) if out is None else out
+        _lib.check(lib.gpbc_gt_exp_batch_dev(_tptr(x), _tptr(k), _sz(n), _tptr(out), _torch_stream()))
+        return out
+    x, k = _np(x, GT_BYTES), _np(k, SCALAR_BYTES)
+    n = x.size // GT_BYTES
+    if k.size // SCALAR_BYTES != n:
+        raise ValueError("one exponent per element")
+    out = np.empty((n, GT_BYTES), dtype=np.uint8)
+    _lib.check(lib.gpbc_gt_exp_batch(_ptr(x), _ptr(k), _sz(n), _ptr(out)))
+    return out
+
+
+def _gt_binary(host_fn, dev_fn, a, b):
+    _ensure_init()
+    if _is_torch(a):
+        n = a.numel() // GT_BYTES
+        out = _tnew(a, n, GT_BYTES)
+        _lib.check(dev_fn(_tptr(a), _tptr(b), _sz(n), _tptr(out), _torch_stream()))
+        return out
+    a, b = _np(a, GT_BYTES), _np(b, GT_BYTES)
+    n = a.size // GT_BYTES
+    if b.size != a.size:
+        raise ValueError("operand sizes differ")
+    out = np.empty((n, GT_BYTES), dtype=np.uint8)
+    _lib.check(host_fn(_ptr(a), _ptr(b), _sz(n), _ptr(out)))
+    return out
+
+
+def gt_mul(a, b):
+    lib = _lib.load()
+    return _gt_binary(lib.gpbc_gt_mul_batch, lib.gpbc_gt_mul_batch_dev, a, b)
+
+
+def gt_div(a, b):
+    lib = _lib.load()
+    return _gt_binary(lib.gpbc_gt_div_batch, lib.gpbc_gt_div_batch_dev, a, b)
+
+
+def gt_inverse(a):
+    _ensure_init()
+    lib = _lib.load()
+    if _is_torch(a):
+        n = a.numel() // GT_BYTES
+        out = _tnew(a, n, GT_BYTES)
+        _lib.check(lib.gpbc_gt_inverse_batch_dev(_tptr(a), _sz(n), _tptr(out), _torch_stream()))
+        return out
+    a = _np(a, GT_BYTES)
+    n = a.size // GT_BYTES
+    out = np.empty((n, GT_BYTES), dtype=np.uint8)
+    _lib.check(lib.gpbc_gt_inverse_batch(_ptr(a), _sz(n), _ptr(out)))
+    return out
+
+
+def fp_mul(a, b):
+    """Batched Fp Montgomery product (kernel unit test entry)."""
+    _ensure_init()
+    lib = _lib.load()
+    a, b = _np(a, 32), _np(b, 32)
+    n = a.size // 32
+    out = np.empty((n, 32), dtype=np.uint8)
+    _lib.check(lib.gpbc_fp_mul_batch(_ptr(a), _ptr(b), _sz(n), _ptr(out)))
+    return out

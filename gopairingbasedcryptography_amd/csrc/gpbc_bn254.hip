@@ -1,0 +1,476 @@
+// libgpbc_bn254.so — kernels and C ABI (include/gpbc_bn254.h) of the MI355X BN254 engine.
+// gfx950 only. One batch element per lane; ABI buffers are gnark in-memory structs (AoS).
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include "../../include/gpbc_bn254.h"
+#include "curve.cuh"
+#include "pairing.cuh"
+
+using namespace gpbc;
+
+// =============================================================================================== kernels
+constexpr int BLOCK = 64;
+
+__global__ void __launch_bounds__(BLOCK) k_miller_loop(const uint8_t *__restrict__ P, const uint8_t *__restrict__ Q,
+                                                       uint8_t *__restrict__ f_out, size_t n) {
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    G1Aff p = g1_load(P + i * GPBC_G1_BYTES);
+    G2Aff q = g2_load(Q + i * GPBC_G2_BYTES);
+    Fp12 f;
+    if (g1_is_inf(p) || g2_is_inf(q)) fp12_set_one(f);
+    else miller_loop(f, p, q);
+    fp12_store(f_out + i * GPBC_GT_BYTES, f);
+}
+
+__global__ void __launch_bounds__(BLOCK) k_final_exp(const uint8_t *f_in, uint8_t *gt_out, size_t n) {
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    Fp12 f, z;
+    fp12_load(f, f_in + i * GPBC_GT_BYTES);
+    final_exp(z, f);
+    fp12_store(gt_out + i * GPBC_GT_BYTES, z);
+}
+
+// product of the Miller functions of each segment: thread j multiplies f[seg_off[j] .. seg_off[j+1])
+__global__ void __launch_bounds__(BLOCK) k_segment_product(const uint8_t *__restrict__ f, const uint64_t *__restrict__ seg_off,
+                                                           uint8_t *__restrict__ out, size_t k) {
+    size_t j = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= k) return;
+    Fp12 acc, t;
+    fp12_set_one(acc);
+    uint64_t lo = seg_off[j], hi = seg_off[j + 1];
+    for (uint64_t i = lo; i < hi; i++) {
+        fp12_load(t, f + i * GPBC_GT_BYTES);
+        if (i == lo) acc = t; else fp12_mul(acc, acc, t);
+    }
+    fp12_store(out + j * GPBC_GT_BYTES, acc);
+}
+
+__global__ void __launch_bounds__(BLOCK) k_gt_is_one(const uint8_t *__restrict__ gt, uint8_t *__restrict__ ok, size_t n) {
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    Fp12 z;
+    fp12_load(z, gt + i * GPBC_GT_BYTES);
+    ok[i] = fp12_is_one(z) ? 1 : 0;
+}
+
+__device__ __forceinline__ void load_scalar(u32 k[8], const uint8_t *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    uint4 a = q[0], b = q[1];
+    k[0] = a.x; k[1] = a.y; k[2] = a.z; k[3] = a.w; k[4] = b.x; k[5] = b.y; k[6] = b.z; k[7] = b.w;
+}
+
+__global__ void __launch_bounds__(BLOCK) k_g1_scalar_mul(const uint8_t *__restrict__ bases, int shared_base,
+                                                         const uint8_t *__restrict__ scalars, uint8_t *__restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t *bp = bases + (shared_base ? 0 : i * GPBC_G1_BYTES);
+    Aff<Fp> b{fp_load(bp), fp_load(bp + 32)}, r;
+    u32 k[8];
+    load_scalar(k, scalars + i * GPBC_SCALAR_BYTES);
+    scalar_mul<Fp>(r, b, k);
+    fp_store(out + i * GPBC_G1_BYTES, r.x);
+    fp_store(out + i * GPBC_G1_BYTES + 32, r.y);
+}
+
+__global__ void __launch_bounds__(BLOCK) k_g2_scalar_mul(const uint8_t *__restrict__ bases, int shared_base,
+                                                         const uint8_t *__restrict__ scalars, uint8_t *__restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t *bp = bases + (shared_base ? 0 : i * GPBC_G2_BYTES);
+    Aff<Fp2> b{fp2_load(bp), fp2_load(bp + 64)}, r;
+    u32 k[8];
+    load_scalar(k, scalars + i * GPBC_SCALAR_BYTES);
+    scalar_mul<Fp2>(r, b, k);
+    fp2_store(out + i * GPBC_G2_BYTES, r.x);
+    fp2_store(out + i * GPBC_G2_BYTES + 64, r.y);
+}
+
+// one level of the point-sum tree: thread t adds in[t], in[t+n_out], in[t+2 n_out], ... -> out[t] (affine)
+__global__ void __launch_bounds__(BLOCK) k_g1_sum_level(const uint8_t *__restrict__ in, size_t n_in, uint8_t *__restrict__ out, size_t n_out) {
+    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= n_out) return;
+    Jac<Fp> acc;
+    jac_set_inf(acc);
+    for (size_t i = t; i < n_in; i += n_out) {
+        Aff<Fp> q{fp_load(in + i * GPBC_G1_BYTES), fp_load(in + i * GPBC_G1_BYTES + 32)};
+        jac_add_mixed(acc, acc, q);
+    }
+    Aff<Fp> r;
+    jac_to_affine(r, acc);
+    fp_store(out + t * GPBC_G1_BYTES, r.x);
+    fp_store(out + t * GPBC_G1_BYTES + 32, r.y);
+}
+__global__ void __launch_bounds__(BLOCK) k_g2_sum_level(const uint8_t *__restrict__ in, size_t n_in, uint8_t *__restrict__ out, size_t n_out) {
+    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= n_out) return;
+    Jac<Fp2> acc;
+    jac_set_inf(acc);
+    for (size_t i = t; i < n_in; i += n_out) {
+        Aff<Fp2> q{fp2_load(in + i * GPBC_G2_BYTES), fp2_load(in + i * GPBC_G2_BYTES + 64)};
+        jac_add_mixed(acc, acc, q);
+    }
+    Aff<Fp2> r;
+    jac_to_affine(r, acc);
+    fp2_store(out + t * GPBC_G2_BYTES, r.x);
+    fp2_store(out + t * GPBC_G2_BYTES + 64, r.y);
+}
+
+// GT.Exp: left-to-right square-and-multiply on a 256-bit plain exponent (k = 0 -> one)
+__global__ void __launch_bounds__(BLOCK) k_gt_exp(const uint8_t *__restrict__ x, const uint8_t *__restrict__ kk, uint8_t *__restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    Fp12 b, r;
+    fp12_load(b, x + i * GPBC_GT_BYTES);
+    u32 k[8];
+    load_scalar(k, kk + i * GPBC_SCALAR_BYTES);
+    int top = 255;
+    while (top >= 0 && !((k[top >> 5] >> (top & 31)) & 1)) top--;
+    if (top < 0) fp12_set_one(r);
+    else {
+        r = b;
+        for (int j = top - 1; j >= 0; j--) {
+            fp12_sqr(r, r);
+            if ((k[j >> 5] >> (j & 31)) & 1) fp12_mul(r, r, b);
+        }
+    }
+    fp12_store(out + i * GPBC_GT_BYTES, r);
+}
+
+// op 0: a*b   1: a*b^-1   2: a^-1
+__global__ void __launch_bounds__(BLOCK) k_gt_binary(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, uint8_t *__restrict__ out, size_t n, int op) {
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    Fp12 x, y, z;
+    fp12_load(x, a + i * GPBC_GT_BYTES);
+    if (op == 2) fp12_inv(z, x);
+    else {
+        fp12_load(y, b + i * GPBC_GT_BYTES);
+        if (op == 1) fp12_inv(y, y);
+        fp12_mul(z, x, y);
+    }
+    fp12_store(out + i * GPBC_GT_BYTES, z);
+}
+
+__global__ void __launch_bounds__(BLOCK) k_fp_mul(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, uint8_t *__restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    fp_store(out + i * 32, fp_mul(fp_load(a + i * 32), fp_load(b + i * 32)));
+}
+
+// =============================================================================================== host side
+static thread_local char g_err[512] = "";
+static std::atomic<int> g_device{-1};
+
+static int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(GPBC_ERR_HIP, "%s failed: %s", #x, hipGetErrorString(e_)); } while (0)
+
+static int bind_device() {
+    int d = g_device.load();
+    if (d < 0) return fail(GPBC_ERR_NO_DEVICE, "gpbc_init() has not bound a HIP device (no CPU fallback exists)");
+    HIP_TRY(hipSetDevice(d));
+    return GPBC_OK;
+}
+static inline unsigned grid_for(size_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
+static int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GPBC_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+    return GPBC_OK;
+}
+#define TRY(x) do { int rc_ = (x); if (rc_ != GPBC_OK) return rc_; } while (0)
+
+// RAII device buffer for the host-pointer entry points
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) {
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+        if (e != hipSuccess) { p = nullptr; return fail(GPBC_ERR_HIP, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
+        return GPBC_OK;
+    }
+    int upload(const void *src, size_t bytes) {
+        TRY(alloc(bytes));
+        if (bytes) HIP_TRY(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+        return GPBC_OK;
+    }
+    int download(void *dst, size_t bytes) const {
+        if (bytes) HIP_TRY(hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost));
+        return GPBC_OK;
+    }
+    uint8_t *u8() const { return static_cast<uint8_t *>(p); }
+};
+
+extern "C" {
+
+int gpbc_abi_version(void) { return 1; }
+const char *gpbc_last_error(void) { return g_err; }
+
+int gpbc_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(GPBC_ERR_NO_DEVICE, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+    return n;
+}
+
+int gpbc_init(int device) {
+    int n = gpbc_device_count();
+    if (n <= 0) return fail(GPBC_ERR_NO_DEVICE, "no HIP device visible (this engine has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(GPBC_ERR_INVALID_ARG, "device %d out of range [0,%d)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(GPBC_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
+    g_device.store(device);
+    return GPBC_OK;
+}
+
+int gpbc_shutdown(void) {
+    g_device.store(-1);
+    return GPBC_OK;
+}
+
+// ----------------------------------------------------------------------------------------------- device-pointer API
+int gpbc_miller_loop_dev(const void *dP, const void *dQ, size_t n, void *d_f_out, void *stream) {
+    if (!n) return GPBC_OK;
+    if (!dP || !dQ || !d_f_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    TRY(bind_device());
+    k_miller_loop<<<grid_for(n), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)dP, (const uint8_t *)dQ, (uint8_t *)d_f_out, n);
+    return check_launch("k_miller_loop");
+}
+int gpbc_final_exp_dev(const void *d_f, size_t n, void *d_gt_out, void *stream) {
+    if (!n) return GPBC_OK;
+    if (!d_f || !d_gt_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    TRY(bind_device());
+    k_final_exp<<<grid_for(n), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_f, (uint8_t *)d_gt_out, n);
+    return check_launch("k_final_exp");
+}
+int gpbc_pair_batch_dev(const void *dP, const void *dQ, size_t n, void *d_gt_out, void *stream) {
+    if (!n) return fail(GPBC_ERR_INVALID_ARG, "invalid inputs sizes");
+    TRY(gpbc_miller_loop_dev(dP, dQ, n, d_gt_out, stream));        // f staged in the output buffer
+    return gpbc_final_exp_dev(d_gt_out, n, d_gt_out, stream);      // each lane rewrites its own 384 B
+}
+size_t gpbc_multi_pair_workspace_bytes(size_t n_pairs, size_t k) { (void)k; return n_pairs * GPBC_GT_BYTES; }
+int gpbc_multi_pair_dev(const void *dP, const void *dQ, const uint64_t *d_seg_off, size_t n_pairs, size_t k,
+                        void *d_gt_out, void *d_workspace, size_t workspace_bytes, void *stream) {
+    if (!k) return fail(GPBC_ERR_INVALID_ARG, "invalid inputs sizes");
+    if (!d_seg_off || !d_gt_out || (n_pairs && (!dP || !dQ || !d_workspace))) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    if (workspace_bytes < gpbc_multi_pair_workspace_bytes(n_pairs, k)) return fail(GPBC_ERR_WORKSPACE, "workspace too small");
+    TRY(gpbc_miller_loop_dev(dP, dQ, n_pairs, d_workspace, stream));
+    k_segment_product<<<grid_for(k), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_workspace, d_seg_off, (uint8_t *)d_gt_out, k);
+    TRY(check_launch("k_segment_product"));
+    return gpbc_final_exp_dev(d_gt_out, k, d_gt_out, stream);
+}
+static int scalar_mul_dev(bool g2, const void *d_bases, size_t nbase, const void *d_scalars, size_t n, void *d_out, void *stream) {
+    if (!n) return GPBC_OK;
+    if (!d_bases || !d_scalars || !d_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    if (nbase != 1 && nbase != n) return fail(GPBC_ERR_INVALID_ARG, "nbase must be 1 or n");
+    TRY(bind_device());
+    int shared = (nbase == 1 && n != 1) ? 1 : 0;
+    if (g2) k_g2_scalar_mul<<<grid_for(n), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_bases, shared, (const uint8_t *)d_scalars, (uint8_t *)d_out, n);
+    else k_g1_scalar_mul<<<grid_for(n), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_bases, shared, (const uint8_t *)d_scalars, (uint8_t *)d_out, n);
+    return check_launch(g2 ? "k_g2_scalar_mul" : "k_g1_scalar_mul");
+}
+int gpbc_g1_scalar_mul_batch_dev(const void *b, size_t nb, const void *s, size_t n, void *o, void *st) { return scalar_mul_dev(false, b, nb, s, n, o, st); }
+int gpbc_g2_scalar_mul_batch_dev(const void *b, size_t nb, const void *s, size_t n, void *o, void *st) { return scalar_mul_dev(true, b, nb, s, n, o, st); }
+
+constexpr size_t SUM_FANIN = 32;
+size_t gpbc_sum_workspace_bytes(size_t n, int is_g2) {
+    size_t pt = is_g2 ? GPBC_G2_BYTES : GPBC_G1_BYTES, total = 0;
+    while (n > 1) { n = (n + SUM_FANIN - 1) / SUM_FANIN; total += n * pt; }
+    return total + pt;
+}
+static int sum_dev(bool g2, const void *d_pts, size_t n, void *d_out, void *d_ws, size_t ws_bytes, void *stream) {
+    if (!d_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    TRY(bind_device());
+    size_t pt = g2 ? GPBC_G2_BYTES : GPBC_G1_BYTES;
+    if (!n) { HIP_TRY(hipMemsetAsync(d_out, 0, pt, (hipStream_t)stream)); return GPBC_OK; }
+    if (!d_pts || !d_ws) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    if (ws_bytes < gpbc_sum_workspace_bytes(n, g2)) return fail(GPBC_ERR_WORKSPACE, "workspace too small");
+    const uint8_t *in = (const uint8_t *)d_pts;
+    uint8_t *ws = (uint8_t *)d_ws;
+    size_t n_in = n;
+    for (;;) {
+        size_t n_out = (n_in + SUM_FANIN - 1) / SUM_FANIN;
+        uint8_t *out = n_out == 1 ? (uint8_t *)d_out : ws;
+        if (g2) k_g2_sum_level<<<grid_for(n_out), BLOCK, 0, (hipStream_t)stream>>>(in, n_in, out, n_out);
+        else k_g1_sum_level<<<grid_for(n_out), BLOCK, 0, (hipStream_t)stream>>>(in, n_in, out, n_out);
+        TRY(check_launch("k_sum_level"));
+        if (n_out == 1) break;
+        in = out; ws += n_out * pt; n_in = n_out;
+    }
+    return GPBC_OK;
+}
+int gpbc_g1_sum_dev(const void *p, size_t n, void *o, void *w, size_t wb, void *s) { return sum_dev(false, p, n, o, w, wb, s); }
+int gpbc_g2_sum_dev(const void *p, size_t n, void *o, void *w, size_t wb, void *s) { return sum_dev(true, p, n, o, w, wb, s); }
+
+int gpbc_gt_exp_batch_dev(const void *d_x, const void *d_k, size_t n, void *d_out, void *stream) {
+    if (!n) return GPBC_OK;
+    if (!d_x || !d_k || !d_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    TRY(bind_device());
+    k_gt_exp<<<grid_for(n), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_x, (const uint8_t *)d_k, (uint8_t *)d_out, n);
+    return check_launch("k_gt_exp");
+}
+static int gt_binary_dev(int op, const void *a, const void *b, size_t n, void *out, void *stream) {
+    if (!n) return GPBC_OK;
+    if (!a || (op != 2 && !b) || !out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    TRY(bind_device());
+    k_gt_binary<<<grid_for(n), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)a, (const uint8_t *)b, (uint8_t *)out, n, op);
+    return check_launch("k_gt_binary");
+}
+int gpbc_gt_mul_batch_dev(const void *a, const void *b, size_t n, void *o, void *s) { return gt_binary_dev(0, a, b, n, o, s); }
+int gpbc_gt_div_batch_dev(const void *a, const void *b, size_t n, void *o, void *s) { return gt_binary_dev(1, a, b, n, o, s); }
+int gpbc_gt_inverse_batch_dev(const void *a, size_t n, void *o, void *s) { return gt_binary_dev(2, a, nullptr, n, o, s); }
+
+// ----------------------------------------------------------------------------------------------- host-pointer API
+static int sync_default() { HIP_TRY(hipStreamSynchronize(nullptr)); return GPBC_OK; }
+
+int gpbc_miller_loop(const void *P, const void *Q, size_t n, void *f_out) {
+    if (!n) return GPBC_OK;
+    if (!P || !Q || !f_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    TRY(bind_device());
+    DevBuf dP, dQ, dF;
+    TRY(dP.upload(P, n * GPBC_G1_BYTES)); TRY(dQ.upload(Q, n * GPBC_G2_BYTES)); TRY(dF.alloc(n * GPBC_GT_BYTES));
+    TRY(gpbc_miller_loop_dev(dP.p, dQ.p, n, dF.p, nullptr));
+    TRY(sync_default());
+    return dF.download(f_out, n * GPBC_GT_BYTES);
+}
+int gpbc_final_exp(const void *f, size_t n, void *gt_out) {
+    if (!n) return GPBC_OK;
+    if (!f || !gt_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    TRY(bind_device());
+    DevBuf dF;
+    TRY(dF.upload(f, n * GPBC_GT_BYTES));
+    TRY(gpbc_final_exp_dev(dF.p, n, dF.p, nullptr));
+    TRY(sync_default());
+    return dF.download(gt_out, n * GPBC_GT_BYTES);
+}
+int gpbc_pair_batch(const void *P, const void *Q, size_t n, void *gt_out) {
+    if (!n) return fail(GPBC_ERR_INVALID_ARG, "invalid inputs sizes");
+    if (!P || !Q || !gt_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    TRY(bind_device());
+    DevBuf dP, dQ, dG;
+    TRY(dP.upload(P, n * GPBC_G1_BYTES)); TRY(dQ.upload(Q, n * GPBC_G2_BYTES)); TRY(dG.alloc(n * GPBC_GT_BYTES));
+    TRY(gpbc_pair_batch_dev(dP.p, dQ.p, n, dG.p, nullptr));
+    TRY(sync_default());
+    return dG.download(gt_out, n * GPBC_GT_BYTES);
+}
+static int check_segments(const uint64_t *seg_off, size_t k, size_t *n_pairs) {
+    if (!seg_off) return fail(GPBC_ERR_INVALID_ARG, "null segment table");
+    if (seg_off[0] != 0) return fail(GPBC_ERR_INVALID_ARG, "seg_off[0] must be 0");
+    for (size_t j = 0; j < k; j++)
+        if (seg_off[j + 1] < seg_off[j]) return fail(GPBC_ERR_INVALID_ARG, "segment table not monotone at %zu", j);
+    *n_pairs = (size_t)seg_off[k];
+    return GPBC_OK;
+}
+static int multi_pair_host(const void *P, const void *Q, const uint64_t *seg_off, size_t k, void *gt_out, uint8_t *ok_out) {
+    if (!k) return fail(GPBC_ERR_INVALID_ARG, "invalid inputs sizes");
+    size_t n_pairs = 0;
+    TRY(check_segments(seg_off, k, &n_pairs));
+    if ((n_pairs && (!P || !Q)) || (!gt_out && !ok_out)) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    TRY(bind_device());
+    DevBuf dP, dQ, dS, dG, dW, dOk;
+    TRY(dP.upload(P, n_pairs * GPBC_G1_BYTES)); TRY(dQ.upload(Q, n_pairs * GPBC_G2_BYTES));
+    TRY(dS.upload(seg_off, (k + 1) * sizeof(uint64_t)));
+    TRY(dG.alloc(k * GPBC_GT_BYTES));
+    size_t wsb = gpbc_multi_pair_workspace_bytes(n_pairs, k);
+    TRY(dW.alloc(wsb));
+    TRY(gpbc_multi_pair_dev(dP.p, dQ.p, (const uint64_t *)dS.p, n_pairs, k, dG.p, dW.p, wsb, nullptr));
+    if (ok_out) {
+        TRY(dOk.alloc(k));
+        k_gt_is_one<<<grid_for(k), BLOCK>>>(dG.u8(), dOk.u8(), k);
+        TRY(check_launch("k_gt_is_one"));
+    }
+    TRY(sync_default());
+    if (gt_out) TRY(dG.download(gt_out, k * GPBC_GT_BYTES));
+    if (ok_out) TRY(dOk.download(ok_out, k));
+    return GPBC_OK;
+}
+int gpbc_multi_pair(const void *P, const void *Q, const uint64_t *seg_off, size_t k, void *gt_out) {
+    if (!gt_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    return multi_pair_host(P, Q, seg_off, k, gt_out, nullptr);
+}
+int gpbc_pairing_check(const void *P, const void *Q, const uint64_t *seg_off, size_t k, uint8_t *ok_out) {
+    if (!ok_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    return multi_pair_host(P, Q, seg_off, k, nullptr, ok_out);
+}
+static int scalar_mul_host(bool g2, const void *bases, size_t nbase, const void *scalars, size_t n, void *out) {
+    if (!n) return GPBC_OK;
+    if (!bases || !scalars || !out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    if (nbase != 1 && nbase != n) return fail(GPBC_ERR_INVALID_ARG, "nbase must be 1 or n");
+    TRY(bind_device());
+    size_t pt = g2 ? GPBC_G2_BYTES : GPBC_G1_BYTES;
+    DevBuf dB, dS, dO;
+    TRY(dB.upload(bases, nbase * pt)); TRY(dS.upload(scalars, n * GPBC_SCALAR_BYTES)); TRY(dO.alloc(n * pt));
+    TRY(scalar_mul_dev(g2, dB.p, nbase, dS.p, n, dO.p, nullptr));
+    TRY(sync_default());
+    return dO.download(out, n * pt);
+}
+int gpbc_g1_scalar_mul_batch(const void *b, size_t nb, const void *s, size_t n, void *o) { return scalar_mul_host(false, b, nb, s, n, o); }
+int gpbc_g2_scalar_mul_batch(const void *b, size_t nb, const void *s, size_t n, void *o) { return scalar_mul_host(true, b, nb, s, n, o); }
+
+static int sum_host(bool g2, const void *pts, size_t n, void *out) {
+    if (!out || (n && !pts)) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    TRY(bind_device());
+    size_t pt = g2 ? GPBC_G2_BYTES : GPBC_G1_BYTES;
+    DevBuf dP, dO, dW;
+    TRY(dP.upload(pts, n * pt)); TRY(dO.alloc(pt));
+    size_t wsb = gpbc_sum_workspace_bytes(n, g2);
+    TRY(dW.alloc(wsb));
+    TRY(sum_dev(g2, dP.p, n, dO.p, dW.p, wsb, nullptr));
+    TRY(sync_default());
+    return dO.download(out, pt);
+}
+int gpbc_g1_sum(const void *p, size_t n, void *o) { return sum_host(false, p, n, o); }
+int gpbc_g2_sum(const void *p, size_t n, void *o) { return sum_host(true, p, n, o); }
+
+int gpbc_gt_exp_batch(const void *x, const void *k, size_t n, void *out) {
+    if (!n) return GPBC_OK;
+    if (!x || !k || !out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    TRY(bind_device());
+    DevBuf dX, dK, dO;
+    TRY(dX.upload(x, n * GPBC_GT_BYTES)); TRY(dK.upload(k, n * GPBC_SCALAR_BYTES)); TRY(dO.alloc(n * GPBC_GT_BYTES));
+    TRY(gpbc_gt_exp_batch_dev(dX.p, dK.p, n, dO.p, nullptr));
+    TRY(sync_default());
+    return dO.download(out, n * GPBC_GT_BYTES);
+}
+static int gt_binary_host(int op, const void *a, const void *b, size_t n, void *out) {
+    if (!n) return GPBC_OK;
+    if (!a || (op != 2 && !b) || !out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    TRY(bind_device());
+    DevBuf dA, dB, dO;
+    TRY(dA.upload(a, n * GPBC_GT_BYTES));
+    if (op != 2) TRY(dB.upload(b, n * GPBC_GT_BYTES));
+    TRY(dO.alloc(n * GPBC_GT_BYTES));
+    TRY(gt_binary_dev(op, dA.p, dB.p, n, dO.p, nullptr));
+    TRY(sync_default());
+    return dO.download(out, n * GPBC_GT_BYTES);
+}
+int gpbc_gt_mul_batch(const void *a, const void *b, size_t n, void *o) { return gt_binary_host(0, a, b, n, o); }
+int gpbc_gt_div_batch(const void *a, const void *b, size_t n, void *o) { return gt_binary_host(1, a, b, n, o); }
+int gpbc_gt_inverse_batch(const void *a, size_t n, void *o) { return gt_binary_host(2, a, nullptr, n, o); }
+
+int gpbc_fp_mul_batch(const void *a, const void *b, size_t n, void *out) {
+    if (!n) return GPBC_OK;
+    if (!a || !b || !out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    TRY(bind_device());
+    DevBuf dA, dB, dO;
+    TRY(dA.upload(a, n * 32)); TRY(dB.upload(b, n * 32)); TRY(dO.alloc(n * 32));
+    k_fp_mul<<<grid_for(n), BLOCK>>>(dA.u8(), dB.u8(), dO.u8(), n);
+    TRY(check_launch("k_fp_mul"));
+    TRY(sync_default());
+    return dO.download(out, n * 32);
+}
+
+}  // extern "C"

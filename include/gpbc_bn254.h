@@ -1,0 +1,118 @@
+/* gpbc_bn254.h — C ABI of the MI355X batched BN254 pairing engine (libgpbc_bn254.so).
+ *
+ * Drop-in boundary for the gnark-crypto calls the reference (mmsyan/GoPairingBasedCryptography) makes on
+ * its hot path.  The reference has no FFI of its own: it calls github.com/consensys/gnark-crypto v0.19.0
+ * (go.mod:5) directly.  A cgo shim binds the functions below in place of those calls;
+ * each entry names the reference call sites it replaces.
+ *
+ * Data layouts = gnark-crypto in-memory structs, so Go slices are passed without conversion:
+ *   fp.Element   4 x uint64 little-endian limbs, Montgomery form (x * 2^256 mod p)          32 B
+ *   G1Affine     {X, Y fp.Element}; point at infinity = all zero                             64 B
+ *   G2Affine     {X, Y E2{A0, A1}}                                                          128 B
+ *   GT (E12)     {C0, C1 E6{B0, B1, B2 E2{A0, A1}}}                                         384 B
+ *   scalar       32-byte little-endian plain (non-Montgomery) integer, any value < 2^256
+ *                (the shim fills it from big.Int; values >= r act as their residue mod r)
+ *
+ * Conventions: every function returns 0 on success and a negative gpbc_status on failure and never
+ * aborts; gpbc_last_error() gives a thread-local message.  Buffers are caller-owned.  Functions are
+ * thread-safe.  There is NO CPU fallback: without a usable gfx950 device every compute entry fails
+ * with GPBC_ERR_NO_DEVICE.
+ *
+ * *_dev variants take device pointers (buffers already resident in HBM), enqueue on `stream`
+ * (a hipStream_t passed as void*, NULL = default stream) and return without synchronising.
+ */
+#ifndef GPBC_BN254_H
+#define GPBC_BN254_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPBC_G1_BYTES 64
+#define GPBC_G2_BYTES 128
+#define GPBC_GT_BYTES 384
+#define GPBC_SCALAR_BYTES 32
+
+typedef enum {
+    GPBC_OK = 0,
+    GPBC_ERR_INVALID_ARG = -1,   /* null pointer, n == 0 where gnark errors ("invalid inputs sizes"), bad segment table */
+    GPBC_ERR_NO_DEVICE = -2,     /* no HIP device / gpbc_init not successful */
+    GPBC_ERR_HIP = -3,           /* a HIP runtime call failed; see gpbc_last_error() */
+    GPBC_ERR_WORKSPACE = -4      /* *_dev call given a workspace smaller than gpbc_*_workspace_bytes() */
+} gpbc_status;
+
+/* ---- lifetime --------------------------------------------------------------------------------- */
+int gpbc_init(int device);                 /* bind this process to HIP device `device`; idempotent */
+int gpbc_shutdown(void);
+const char *gpbc_last_error(void);         /* thread-local, never NULL */
+int gpbc_device_count(void);               /* number of visible HIP devices, <0 on error */
+int gpbc_abi_version(void);
+
+/* ---- pairings ----------------------------------------------------------------------------------
+ * bn254.Pair(P []G1Affine, Q []G2Affine) (GT, error) with len==1, n times
+ *   (cpabe/bsw07/bsw07_cpabe.go:75,184; access/tree/access_tree_node.go:106,110,119;
+ *    bibe/afp25_bibe/afp25_bibe.go:227,395,399,403; ibe/bb04_ibe/bb04_ibe.go:215,225; ...).
+ * A pair with the point at infinity in either slot yields GT one. */
+int gpbc_pair_batch(const void *P, const void *Q, size_t n, void *gt_out);
+int gpbc_pair_batch_dev(const void *dP, const void *dQ, size_t n, void *d_gt_out, void *stream);
+
+/* bn254.Pair with len>1, k times: segment j is pairs [seg_off[j], seg_off[j+1]); one Miller loop per
+ * pair, one final exponentiation per segment (products assembled by callers: ibe/bb04_ibe/bb04_ibe.go:213-225,
+ * access/tree/access_tree_node.go:106-157, bibe/afp25_bibe/afp25_bibe.go:395-413).
+ * seg_off has k+1 non-decreasing entries, seg_off[0] == 0; an empty segment yields GT one. */
+int gpbc_multi_pair(const void *P, const void *Q, const uint64_t *seg_off, size_t k, void *gt_out);
+size_t gpbc_multi_pair_workspace_bytes(size_t n_pairs, size_t k);
+int gpbc_multi_pair_dev(const void *dP, const void *dQ, const uint64_t *d_seg_off, size_t n_pairs, size_t k,
+                        void *d_gt_out, void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* bn254.PairingCheck(P, Q) (bool, error), k times (signature/bls01_signature/bls_signature.go:81):
+ * ok_out[j] = 1 iff the product over segment j is GT one. */
+int gpbc_pairing_check(const void *P, const void *Q, const uint64_t *seg_off, size_t k, uint8_t *ok_out);
+
+/* stages of Pair, exposed for parity tests and profiling: the Miller function (before the final
+ * exponentiation; defined up to factors the final exponentiation removes) and the exponentiation alone */
+int gpbc_miller_loop_dev(const void *dP, const void *dQ, size_t n, void *d_f_out, void *stream);
+int gpbc_final_exp_dev(const void *d_f, size_t n, void *d_gt_out, void *stream);
+int gpbc_miller_loop(const void *P, const void *Q, size_t n, void *f_out);
+int gpbc_final_exp(const void *f, size_t n, void *gt_out);
+
+/* ---- scalar multiplication ---------------------------------------------------------------------
+ * (*G1Affine).ScalarMultiplication(a, s) / ScalarMultiplicationBase(s), n times
+ *   (signature/bls01_signature/bls_signature.go:45; cpabe/bsw07/bsw07_cpabe.go:69,149,157,160;
+ *    bibe/afp25_bibe/afp25_bibe_utils.go:48,51).  nbase == n: one base per scalar; nbase == 1: shared base. */
+int gpbc_g1_scalar_mul_batch(const void *bases, size_t nbase, const void *scalars, size_t n, void *out);
+int gpbc_g1_scalar_mul_batch_dev(const void *d_bases, size_t nbase, const void *d_scalars, size_t n, void *d_out, void *stream);
+/* (*G2Affine).ScalarMultiplication(a, s) (signature/bls01_signature/bls_signature.go:63;
+ *  cpabe/bsw07/bsw07_cpabe.go:73,83,103-121; bibe/afp25_bibe/afp25_bibe.go:215,250,251) */
+int gpbc_g2_scalar_mul_batch(const void *bases, size_t nbase, const void *scalars, size_t n, void *out);
+int gpbc_g2_scalar_mul_batch_dev(const void *d_bases, size_t nbase, const void *d_scalars, size_t n, void *d_out, void *stream);
+
+/* sum of n affine points -> one affine point (G1Affine.Add chains: bibe/afp25_bibe/afp25_bibe_utils.go:52,
+ * gka/agka09/asbb.go:193-220; the aggregate-verify path of BASELINE config 3) */
+int gpbc_g1_sum(const void *pts, size_t n, void *out);
+int gpbc_g2_sum(const void *pts, size_t n, void *out);
+size_t gpbc_sum_workspace_bytes(size_t n, int is_g2);
+int gpbc_g1_sum_dev(const void *d_pts, size_t n, void *d_out, void *d_workspace, size_t workspace_bytes, void *stream);
+int gpbc_g2_sum_dev(const void *d_pts, size_t n, void *d_out, void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* ---- GT arithmetic -----------------------------------------------------------------------------
+ * (*GT).Exp(x, k) for k >= 0 (access/tree/access_tree_node.go:123,156; bibe/afp25_bibe/afp25_bibe.go:258-259);
+ * the shim maps a negative big.Int to Inverse followed by Exp(|k|), as gnark does. */
+int gpbc_gt_exp_batch(const void *x, const void *k, size_t n, void *out);
+int gpbc_gt_exp_batch_dev(const void *d_x, const void *d_k, size_t n, void *d_out, void *stream);
+/* (*GT).Mul / Div / Inverse (access/tree/access_tree_node.go:114,157; cpabe/bsw07/bsw07_cpabe.go:189-190) */
+int gpbc_gt_mul_batch(const void *a, const void *b, size_t n, void *out);
+int gpbc_gt_div_batch(const void *a, const void *b, size_t n, void *out);
+int gpbc_gt_inverse_batch(const void *a, size_t n, void *out);
+int gpbc_gt_mul_batch_dev(const void *d_a, const void *d_b, size_t n, void *d_out, void *stream);
+int gpbc_gt_div_batch_dev(const void *d_a, const void *d_b, size_t n, void *d_out, void *stream);
+int gpbc_gt_inverse_batch_dev(const void *d_a, size_t n, void *d_out, void *stream);
+
+/* ---- field-level entry (kernel unit tests) ------------------------------------------------------ */
+int gpbc_fp_mul_batch(const void *a, const void *b, size_t n, void *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

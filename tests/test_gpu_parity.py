@@ -1,0 +1,202 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against
+  * the committed golden vectors (tests/golden, made by the big-integer oracle), and
+  * the C restatement (oracle/) on the same seeded inputs,
+bit for bit.  Edge cases follow gnark's semantics at the boundary: infinity in either
+slot -> GT one, scalar 0 / >= r, length mismatch -> "invalid inputs sizes"."""
+import numpy as np
+import pytest
+
+import bn254_py as o
+from conftest import cat, hx, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from gopairingbasedcryptography_amd import _build, bn254
+    _build.build_library()
+    bn254.init(0)
+    return bn254
+
+
+def scalars(tag, n, start=0):
+    return np.frombuffer(b"".join(o.scalar_to_bytes(o.bench_scalar(tag, start + i)) for i in range(n)), dtype=np.uint8)
+
+
+@pytest.fixture(scope="module")
+def synth(eng, oracle):
+    """P_i=[k('P',i)]g1, Q_i=[k('Q',i)]g2 made by the engine's scalar-mul kernels, checked against the oracle."""
+    n = 192
+    g1, g2 = eng.generators()
+    P = eng.g1_scalar_mul(g1, scalars("P", n))
+    Q = eng.g2_scalar_mul(g2, scalars("Q", n))
+    assert (P == oracle.g1_scalar_mul(g1, scalars("P", n), threads=8)).all()
+    assert (Q == oracle.g2_scalar_mul(g2, scalars("Q", n), threads=8)).all()
+    return P, Q
+
+
+def test_fp_mul_random(eng, oracle):
+    rng = np.random.default_rng(254)
+    n = 4096
+    vals = [int.from_bytes(rng.bytes(32), "little") % o.P for _ in range(2 * n)]
+    vals[0], vals[1], vals[2], vals[3] = 0, o.P - 1, 1, o.P - 1
+    a = np.frombuffer(b"".join(v.to_bytes(32, "little") for v in vals[:n]), dtype=np.uint8)
+    b = np.frombuffer(b"".join(v.to_bytes(32, "little") for v in vals[n:]), dtype=np.uint8)
+    assert (eng.fp_mul(a, b) == oracle.fp_mul(a, b)).all()
+
+
+def test_pairing_golden(eng):
+    g = load_golden("pairing.json")["cases"]
+    out = eng.pair_batch(cat([c["P"] for c in g]), cat([c["Q"] for c in g]))
+    for i, c in enumerate(g):
+        assert out[i].tobytes().hex() == c["GT"], c["note"]
+
+
+def test_pairing_vs_oracle(eng, oracle, synth):
+    P, Q = synth
+    assert (eng.pair_batch(P, Q) == oracle.pair_batch(P, Q, threads=8)).all()
+
+
+def test_stages_vs_oracle(eng, oracle, synth):
+    P, Q = synth[0][:70], synth[1][:70]        # 70: a ragged tail wave (64 + 6)
+    f = eng.miller_loop(P, Q)
+    assert (eng.final_exp(f) == oracle.pair_batch(P, Q, threads=8)).all()
+    # final exponentiation alone, fed the oracle's Miller values
+    fo = oracle.miller_loop(P, Q, threads=8)
+    assert (eng.final_exp(fo) == oracle.final_exp(fo, threads=8)).all()
+
+
+def test_pair_single_call_semantics(eng):
+    """bn254.Pair(P,Q) with len 1 and len>1, and its error on mismatched or empty input."""
+    segs = load_golden("multi_pair.json")["segments"]
+    s = segs[3]
+    assert eng.pair(cat(s["P"]), cat(s["Q"])).tobytes().hex() == s["GT"]
+    g1, g2 = eng.generators()
+    with pytest.raises(ValueError, match="invalid inputs sizes"):
+        eng.pair(np.concatenate([g1, g1]), g2)
+    with pytest.raises(ValueError, match="invalid inputs sizes"):
+        eng.pair(np.zeros(0, dtype=np.uint8), np.zeros(0, dtype=np.uint8))
+
+
+def test_multi_pair_golden(eng):
+    segs = load_golden("multi_pair.json")["segments"]
+    P = cat([h for s in segs for h in s["P"]]); Q = cat([h for s in segs for h in s["Q"]])
+    off = np.cumsum([0] + [len(s["P"]) for s in segs])
+    out = eng.multi_pair(P, Q, off)
+    ok = eng.pairing_check_batch(P, Q, off)
+    for i, s in enumerate(segs):
+        assert out[i].tobytes().hex() == s["GT"], s["note"]
+        assert bool(ok[i]) == s["is_one"], s["note"]
+
+
+def test_multi_pair_ragged_vs_oracle(eng, oracle, synth):
+    P, Q = synth
+    lens = [0, 1, 7, 0, 64, 3, 65, 2, 33, 17]            # includes empty segments
+    off = np.cumsum([0] + lens)
+    n = int(off[-1])
+    assert (eng.multi_pair(P[:n], Q[:n], off) == oracle.multi_pair(P[:n], Q[:n], off, threads=8)).all()
+
+
+def test_bls_verify_flow(eng):
+    """signature/bls01_signature/bls_signature_test.go:8-37 shape: sk, pk=[x]g1, sigma=[x]H, PairingCheck."""
+    g1, g2 = eng.generators()
+    x = o.bench_scalar("bls-sk", 0)
+    H = eng.g2_scalar_mul(g2, [o.bench_scalar("bls-H", 0)])[0]      # stand-in for hash-to-G2 (out of scope)
+    pk = eng.g1_scalar_mul_base([x])[0]
+    sigma = eng.g2_scalar_mul(H, [x])[0]
+    neg_sigma = np.frombuffer(o.g2_to_bytes(o.g2_neg(o.g2_from_bytes(sigma.tobytes()))), dtype=np.uint8)
+    assert eng.pairing_check(np.concatenate([pk, g1]), np.concatenate([H, neg_sigma]))
+    # wrong key / wrong message must fail (bls_signature_test.go:40-72)
+    pk_bad = eng.g1_scalar_mul_base([x + 1])[0]
+    assert not eng.pairing_check(np.concatenate([pk_bad, g1]), np.concatenate([H, neg_sigma]))
+    H_bad = eng.g2_scalar_mul(g2, [o.bench_scalar("bls-H", 1)])[0]
+    assert not eng.pairing_check(np.concatenate([pk, g1]), np.concatenate([H_bad, neg_sigma]))
+
+
+def test_scalar_mul_golden(eng):
+    for name, fn in (("g1_scalar_mul.json", eng.g1_scalar_mul), ("g2_scalar_mul.json", eng.g2_scalar_mul)):
+        g = load_golden(name)["cases"]
+        out = fn(cat([c["base"] for c in g]), cat([c["scalar"] for c in g]))
+        for i, c in enumerate(g):
+            assert out[i].tobytes().hex() == c["out"], (name, i, c["note"])
+
+
+def test_scalar_mul_vs_oracle(eng, oracle, synth):
+    P, Q = synth
+    n = P.shape[0]
+    k = scalars("s", n)
+    assert (eng.g1_scalar_mul(P, k) == oracle.g1_scalar_mul(P, k, threads=8)).all()
+    assert (eng.g2_scalar_mul(Q, k) == oracle.g2_scalar_mul(Q, k, threads=8)).all()
+    # shared base == per-element base
+    assert (eng.g1_scalar_mul(P[0], k) == eng.g1_scalar_mul(np.tile(P[0], n), k)).all()
+
+
+def test_point_sums(eng, oracle, synth):
+    P, Q = synth
+    for n in (1, 2, 31, 32, 33, 192):
+        assert (eng.g1_sum(P[:n]) == oracle.g1_sum(P[:n])).all(), n
+        assert (eng.g2_sum(Q[:n]) == oracle.g2_sum(Q[:n])).all(), n
+    # P + (-P) + inf -> inf
+    neg = np.frombuffer(o.g1_to_bytes(o.g1_neg(o.g1_from_bytes(P[0].tobytes()))), dtype=np.uint8)
+    assert not eng.g1_sum(np.concatenate([P[0], neg, np.zeros(64, dtype=np.uint8)])).any()
+    assert not eng.g1_sum(np.zeros(0, dtype=np.uint8)).any()
+
+
+def test_gt_ops_golden(eng):
+    g = load_golden("gt_ops.json")
+    out = eng.gt_exp(cat([c["x"] for c in g["exp"]]), cat([c["k"] for c in g["exp"]]))
+    for i, c in enumerate(g["exp"]):
+        assert out[i].tobytes().hex() == c["out"], i
+    a, b = cat([c["a"] for c in g["binary"]]), cat([c["b"] for c in g["binary"]])
+    mul, div, inv = eng.gt_mul(a, b), eng.gt_div(a, b), eng.gt_inverse(a)
+    for i, c in enumerate(g["binary"]):
+        assert mul[i].tobytes().hex() == c["mul"]
+        assert div[i].tobytes().hex() == c["div"]
+        assert inv[i].tobytes().hex() == c["inv_a"]
+    # negative exponent = inverse then exp (gnark GT.Exp)
+    x = hx(g["exp"][5]["x"])
+    assert (eng.gt_exp(x, [-7]) == eng.gt_exp(eng.gt_inverse(x), [7])).all()
+
+
+def test_gt_exp_vs_oracle(eng, oracle, synth):
+    P, Q = synth[0][:40], synth[1][:40]
+    gt = eng.pair_batch(P, Q)
+    k = scalars("gtexp", 40)
+    assert (eng.gt_exp(gt, k) == oracle.gt_exp(gt, k, threads=8)).all()
+
+
+def test_bilinearity_property(eng, synth):
+    """e([a]P,[b]Q) == e(P,Q)^(ab) and the restructuring identities of SURVEY §8a-3, all on the GPU."""
+    P, Q = synth[0][:16], synth[1][:16]
+    a = [o.bench_scalar("bil-a", i) for i in range(16)]
+    b = [o.bench_scalar("bil-b", i) for i in range(16)]
+    lhs = eng.pair_batch(eng.g1_scalar_mul(P, a), eng.g2_scalar_mul(Q, b))
+    rhs = eng.gt_exp(eng.pair_batch(P, Q), [x * y % o.R for x, y in zip(a, b)])
+    assert (lhs == rhs).all()
+    # product of 16 pairings with one final exponentiation == product of 16 full pairings
+    one_fe = eng.multi_pair(P, Q, [0, 16])[0]
+    full = eng.pair_batch(P, Q)
+    acc = full[0]
+    for i in range(1, 16):
+        acc = eng.gt_mul(acc, full[i])[0]
+    assert (one_fe == acc).all()
+
+
+def test_device_pointer_path(eng, synth):
+    """HBM-resident buffers through the *_dev entry points on torch's current stream."""
+    import torch
+    P, Q = synth
+    dP = torch.from_numpy(np.ascontiguousarray(P)).cuda()
+    dQ = torch.from_numpy(np.ascontiguousarray(Q)).cuda()
+    host = eng.pair_batch(P, Q)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        dev = eng.pair_batch(dP, dQ)
+        mp = eng.multi_pair(dP, dQ, np.array([0, 5, 5, 192]))
+    s.synchronize()
+    assert (dev.cpu().numpy() == host).all()
+    assert (mp.cpu().numpy() == eng.multi_pair(P, Q, [0, 5, 5, 192])).all()
+    k = torch.from_numpy(scalars("s", P.shape[0]).copy()).cuda()
+    assert (eng.g1_scalar_mul(dP, k).cpu().numpy() == eng.g1_scalar_mul(P, k.cpu().numpy())).all()
+    assert (eng.g1_sum(dP).cpu().numpy() == eng.g1_sum(P)).all()

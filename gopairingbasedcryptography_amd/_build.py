@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgpbc_bn254.so")
 SOURCES = ["gpbc_bn254.hip"]
-HEADERS = ["fp.cuh", "tower.cuh", "curve.cuh", "pairing.cuh", "bn254_constants.cuh"]
+HEADERS = ["fe29.cuh", "tower29.cuh", "curve29.cuh", "pairing29.cuh", "bn254_constants.cuh", "bn254_constants29.cuh"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC"]
 
 

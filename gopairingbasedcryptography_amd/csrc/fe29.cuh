@@ -1,0 +1,407 @@
+// BN254 base field for gfx950, second-generation layout: nine SIGNED 29-bit limbs per element
+// (value = sum v[i] * 2^(29 i)), Montgomery radix R' = 2^261.
+//
+// Why this shape (measured, profiles/r01_microbench_valu.txt): on MI355X v_mad_i64_i32 / v_mad_u64_u32 issue at the
+// same ~4.5 cycles per wave-instruction as a carry-chain add (v_addc_co_u32), while a plain v_add_u32 / v_sub_u32
+// issues at 2.4.  So the cheapest big-integer product is one MAD per limb pair into a 64-bit column accumulator with
+// NO carry handling (29-bit limbs leave 6 spare bits: 18 products of 2^58 plus the reduction terms fit in int64),
+// and field add / sub are nine independent full-rate VALU ops with no carries and no conditional subtract.
+// Limbs and values are allowed to drift (lazy reduction); `fe_norm` is a carry-free re-normalisation; only values
+// leaving the kernel are made canonical in [0,p) and converted to gnark's R = 2^256 Montgomery bytes — which is
+// what makes the outputs bit-identical to the reference's CPU path.
+//
+// Static safety: compiled with -DGPBC_BOUNDS on the host (tools/bounds_check.cpp) every Fe carries data-independent
+// magnitude bounds and every multiplication asserts that its int64 columns cannot overflow.
+#ifndef GPBC_FE29_CUH
+#define GPBC_FE29_CUH
+#include <stdint.h>
+#include <math.h>
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define GPBC_INLINE __host__ __device__ __forceinline__
+#define GPBC_NOINLINE __host__ __device__ __noinline__
+#else
+#define GPBC_INLINE inline
+#define GPBC_NOINLINE
+#endif
+#include "bn254_constants29.cuh"
+
+#ifdef GPBC_BOUNDS
+#include <cassert>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <execinfo.h>
+#define GPBC_B(...) __VA_ARGS__
+#else
+#define GPBC_B(...)
+#endif
+
+namespace gpbc {
+
+constexpr int NL = 9;
+constexpr int LB = 29;
+constexpr int32_t LMASK = (1 << LB) - 1;
+
+struct Fe {
+    int32_t v[NL];
+#ifdef GPBC_BOUNDS
+    double lb[NL];   // |v[i]| <= lb[i]   (data-independent)
+    double vb;       // |value| <= vb * p
+#endif
+};
+
+#ifdef GPBC_BOUNDS
+struct BoundStats { double max_col = 0, max_limb = 0, max_vb = 0; long muls = 0, norms = 0; };
+inline BoundStats &bound_stats() { static BoundStats s; return s; }
+inline void bounds_fail(const char *what, double got, double lim) {
+    fprintf(stderr, "BOUNDS VIOLATION: %s: %.6g exceeds %.6g\n", what, got, lim);
+    void *bt[24];
+    int n = backtrace(bt, 24);
+    backtrace_symbols_fd(bt, n, 2);       // build with -O0 -g -rdynamic to get one frame per tower function
+    abort();
+}
+constexpr double P_OVER_2_232 = 3171407.0;     // ceil(p / 2^232): top-limb magnitude per unit of p
+constexpr double P_OVER_RP = 0.0059081;         // p / 2^261 (rounded up)
+inline void set_class_n(Fe &r, double vb) {     // limbs 0..7 masked to [0,2^29), top limb holds the rest
+    for (int i = 0; i < NL - 1; i++) r.lb[i] = (double)LMASK;
+    r.lb[NL - 1] = vb * P_OVER_2_232 + 2;
+    r.vb = vb;
+    if (r.lb[NL - 1] > bound_stats().max_limb) bound_stats().max_limb = r.lb[NL - 1];
+    if (vb > bound_stats().max_vb) bound_stats().max_vb = vb;
+}
+inline void check_limbs(const Fe &r, const char *what) {
+    for (int i = 0; i < NL; i++) {
+        if (r.lb[i] >= 2147483648.0) bounds_fail(what, r.lb[i], 2147483648.0);
+        if (std::fabs((double)r.v[i]) > r.lb[i]) bounds_fail("tracked bound below actual value", std::fabs((double)r.v[i]), r.lb[i]);
+        if (r.lb[i] > bound_stats().max_limb) bound_stats().max_limb = r.lb[i];
+    }
+}
+#endif
+
+GPBC_INLINE constexpr int32_t f29_p(int i) { constexpr int32_t P[NL] = F29_P; return P[i]; }
+
+GPBC_INLINE Fe fe_const(const int32_t (&c)[NL]) {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.v[i] = c[i];
+    GPBC_B(set_class_n(r, 1.0);)
+    return r;
+}
+GPBC_INLINE Fe fe_zero() {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.v[i] = 0;
+    GPBC_B(for (int i = 0; i < NL; i++) r.lb[i] = 0; r.vb = 0;)
+    return r;
+}
+GPBC_INLINE Fe fe_one() { constexpr int32_t C[NL] = F29_ONE; return fe_const(C); }
+
+// ------------------------------------------------------------------------------------------------ carry-free linear ops
+GPBC_INLINE Fe fe_add(const Fe &a, const Fe &b) {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.v[i] = a.v[i] + b.v[i];
+    GPBC_B(for (int i = 0; i < NL; i++) r.lb[i] = a.lb[i] + b.lb[i]; r.vb = a.vb + b.vb; check_limbs(r, "fe_add limb");)
+    return r;
+}
+GPBC_INLINE Fe fe_sub(const Fe &a, const Fe &b) {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.v[i] = a.v[i] - b.v[i];
+    GPBC_B(for (int i = 0; i < NL; i++) r.lb[i] = a.lb[i] + b.lb[i]; r.vb = a.vb + b.vb; check_limbs(r, "fe_sub limb");)
+    return r;
+}
+GPBC_INLINE Fe fe_neg(const Fe &a) {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.v[i] = -a.v[i];
+    GPBC_B(for (int i = 0; i < NL; i++) r.lb[i] = a.lb[i]; r.vb = a.vb;)
+    return r;
+}
+GPBC_INLINE Fe fe_dbl(const Fe &a) { return fe_add(a, a); }
+
+// Carry-free ("parallel") normalisation: every limb keeps its low 29 bits and receives the carry of the limb
+// below; the top limb is not masked.  Result limbs 0..7 lie in [-2^k, 2^29 + 2^k) for inputs below 2^(29+k).
+GPBC_INLINE Fe fe_norm(const Fe &a) {
+    Fe r;
+    r.v[0] = a.v[0] & LMASK;
+#pragma unroll
+    for (int i = 1; i < NL - 1; i++) r.v[i] = (a.v[i] & LMASK) + (a.v[i - 1] >> LB);
+    r.v[NL - 1] = a.v[NL - 1] + (a.v[NL - 2] >> LB);
+#ifdef GPBC_BOUNDS
+    r.lb[0] = (double)LMASK;
+    // (x & M) is in [0, M]; (y >> 29) is in [-ceil(|y|/2^29), floor(|y|/2^29)]: the magnitude bound is the positive side
+    for (int i = 1; i < NL - 1; i++) r.lb[i] = (double)LMASK + std::floor(a.lb[i - 1] / 536870912.0);
+    r.lb[NL - 1] = a.lb[NL - 1] + std::ceil(a.lb[NL - 2] / 536870912.0);
+    r.vb = a.vb;
+    bound_stats().norms++;
+    check_limbs(r, "fe_norm limb");
+#endif
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------ Montgomery products
+// (a*b [+ c*d]) / 2^261 mod p.  Product scanning into 17 int64 columns (one v_mad_i64_i32 per limb pair),
+// operand-scanning reduction (m_k from column k, then 9 independent MADs), carries by one 64-bit shift per column.
+// Output: limbs 0..7 in [0,2^29), limb 8 signed and small; value in (-eps p, (1+eps) p).
+template <bool TWO>
+GPBC_INLINE Fe fe_mul_core(const Fe &a, const Fe &b, const Fe &c, const Fe &d) {
+#ifdef GPBC_BOUNDS
+    {
+        double worst = 0;
+        for (int k = 0; k < 2 * NL - 1; k++) {
+            double s = 0;
+            for (int i = 0; i < NL; i++) {
+                int j = k - i;
+                if (j < 0 || j >= NL) continue;
+                s += a.lb[i] * b.lb[j];
+                if (TWO) s += c.lb[i] * d.lb[j];
+            }
+            if (s > worst) worst = s;
+        }
+        double total = worst + 9.0 * 536870912.0 * 536870912.0 + 34359738368.0;   // + reduction terms + carry
+        if (total >= 9223372036854775808.0) bounds_fail("fe_mul column", total, 9223372036854775808.0);
+        if (total > bound_stats().max_col) bound_stats().max_col = total;
+        bound_stats().muls++;
+    }
+#endif
+    int64_t col[2 * NL - 1];
+#pragma unroll
+    for (int k = 0; k < 2 * NL - 1; k++) col[k] = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+#pragma unroll
+        for (int j = 0; j < NL; j++) {
+            col[i + j] += (int64_t)a.v[i] * (int64_t)b.v[j];
+            if (TWO) col[i + j] += (int64_t)c.v[i] * (int64_t)d.v[j];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+        if (k) col[k] += col[k - 1] >> LB;
+        int32_t m = (int32_t)(((uint32_t)col[k] * (uint32_t)F29_PINV) & (uint32_t)LMASK);
+#pragma unroll
+        for (int i = 0; i < NL; i++) col[k + i] += (int64_t)m * (int64_t)f29_p(i);
+    }
+    Fe r;
+    int64_t carry = col[NL - 1] >> LB;
+#pragma unroll
+    for (int k = NL; k < 2 * NL - 1; k++) {
+        int64_t t = col[k] + carry;
+        r.v[k - NL] = (int32_t)(t & LMASK);
+        carry = t >> LB;
+    }
+    r.v[NL - 1] = (int32_t)carry;
+#ifdef GPBC_BOUNDS
+    double vb = (a.vb * b.vb + (TWO ? c.vb * d.vb : 0.0)) * P_OVER_RP + 1.0;
+    set_class_n(r, vb);
+    if (r.lb[NL - 1] >= 268435456.0) bounds_fail("fe_mul output top limb", r.lb[NL - 1], 268435456.0);
+    check_limbs(r, "fe_mul output");
+#endif
+    return r;
+}
+
+#define GPBC_ARGS9(x) int32_t x##0, int32_t x##1, int32_t x##2, int32_t x##3, int32_t x##4, int32_t x##5, int32_t x##6, int32_t x##7, int32_t x##8
+#define GPBC_PASS9(x) x.v[0], x.v[1], x.v[2], x.v[3], x.v[4], x.v[5], x.v[6], x.v[7], x.v[8]
+#define GPBC_PACK9(x) Fe{{x##0, x##1, x##2, x##3, x##4, x##5, x##6, x##7, x##8}}
+
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GPBC_BOUNDS)
+// Leaf functions with every limb passed as a scalar argument: scalars go in VGPRs v0..v31 (aggregates larger than
+// 16 dwords would travel through scratch), so the tower above can stay inlined while the ~200 / ~290-instruction
+// multipliers exist once in the code object (I-cache).
+__device__ __noinline__ Fe fe_mul_leaf(GPBC_ARGS9(a), GPBC_ARGS9(b)) {
+    Fe a = GPBC_PACK9(a), b = GPBC_PACK9(b);
+    return fe_mul_core<false>(a, b, a, b);
+}
+__device__ __noinline__ Fe fe_mul2_leaf(GPBC_ARGS9(a), GPBC_ARGS9(b), GPBC_ARGS9(c), GPBC_ARGS9(d)) {
+    Fe a = GPBC_PACK9(a), b = GPBC_PACK9(b), c = GPBC_PACK9(c), d = GPBC_PACK9(d);
+    return fe_mul_core<true>(a, b, c, d);
+}
+GPBC_INLINE Fe fe_mul(const Fe &a, const Fe &b) { return fe_mul_leaf(GPBC_PASS9(a), GPBC_PASS9(b)); }
+GPBC_INLINE Fe fe_mul2(const Fe &a, const Fe &b, const Fe &c, const Fe &d) {
+    return fe_mul2_leaf(GPBC_PASS9(a), GPBC_PASS9(b), GPBC_PASS9(c), GPBC_PASS9(d));
+}
+#else
+GPBC_INLINE Fe fe_mul(const Fe &a, const Fe &b) { return fe_mul_core<false>(a, b, a, b); }
+GPBC_INLINE Fe fe_mul2(const Fe &a, const Fe &b, const Fe &c, const Fe &d) { return fe_mul_core<true>(a, b, c, d); }
+#endif
+GPBC_INLINE Fe fe_sqr(const Fe &a) { return fe_mul(a, a); }
+
+// ------------------------------------------------------------------------------------------------ small multiples
+// 8a with the limbs re-split on the fly (no limb grows beyond 2^29 + 2^(k+3) for |a limbs| < 2^(29+k))
+GPBC_INLINE Fe fe_mul8_norm(const Fe &a) {
+    Fe r;
+    constexpr int32_t M26 = (1 << (LB - 3)) - 1;
+    r.v[0] = (a.v[0] & M26) << 3;
+#pragma unroll
+    for (int i = 1; i < NL - 1; i++) r.v[i] = ((a.v[i] & M26) << 3) + (a.v[i - 1] >> (LB - 3));
+    r.v[NL - 1] = a.v[NL - 1] * 8 + (a.v[NL - 2] >> (LB - 3));
+#ifdef GPBC_BOUNDS
+    r.lb[0] = (double)LMASK;
+    for (int i = 1; i < NL - 1; i++) r.lb[i] = (double)(LMASK - 7) + std::floor(a.lb[i - 1] / 67108864.0);
+    r.lb[NL - 1] = a.lb[NL - 1] * 8 + std::ceil(a.lb[NL - 2] / 67108864.0);
+    r.vb = a.vb * 8;
+    check_limbs(r, "fe_mul8_norm limb");
+#endif
+    return r;
+}
+// a/2 mod p: make the value even with p (parity of the value = parity of limb 0), then shift across limbs
+GPBC_INLINE Fe fe_halve(const Fe &a) {
+    int32_t odd = -(a.v[0] & 1);
+    int32_t t[NL];
+#pragma unroll
+    for (int i = 0; i < NL; i++) t[i] = a.v[i] + (f29_p(i) & odd);
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < NL - 1; i++) r.v[i] = (t[i] >> 1) + ((t[i + 1] & 1) << (LB - 1));
+    r.v[NL - 1] = t[NL - 1] >> 1;
+#ifdef GPBC_BOUNDS
+    for (int i = 0; i < NL; i++) if (a.lb[i] + (double)LMASK >= 2147483648.0) bounds_fail("fe_halve input limb", a.lb[i], 2147483648.0 - LMASK);
+    for (int i = 0; i < NL - 1; i++) r.lb[i] = (a.lb[i] + (double)LMASK) / 2 + 1 + 268435456.0;
+    r.lb[NL - 1] = (a.lb[NL - 1] + (double)f29_p(NL - 1)) / 2 + 1;
+    r.vb = (a.vb + 1) / 2;
+    check_limbs(r, "fe_halve limb");
+#endif
+    return r;
+}
+
+// Value reduction without a multiplication: subtract k*p with k = round(top limb / p_8).  Input: weakly normalised,
+// |value| < 128p.  Output: |value| < 0.51p, limbs 0..7 within +-(2^29 + 2^8).  Used where a small-constant multiple
+// (the non-residue 9+i) would otherwise let the worst-case magnitude compound through the tower.
+GPBC_INLINE Fe fe_reduce(const Fe &a) {
+#ifdef GPBC_BOUNDS
+    if (a.vb >= 128.0) bounds_fail("fe_reduce input value", a.vb, 128.0);
+    for (int i = 0; i < NL - 1; i++) if (a.lb[i] > 536870912.0 + 1024) bounds_fail("fe_reduce input limb (normalise first)", a.lb[i], 536870912.0 + 1024);
+#endif
+    constexpr int32_t P8 = f29_p(NL - 1);
+    int32_t k = (int32_t)rintf((float)a.v[NL - 1] * (1.0f / (float)P8));
+    Fe r;
+    int32_t hi_prev = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        int64_t t = (int64_t)k * (int64_t)f29_p(i);
+        int32_t lo = (int32_t)(t & LMASK), hi = (int32_t)(t >> LB);
+        r.v[i] = (i < NL - 1) ? a.v[i] - lo - hi_prev : a.v[i] - (int32_t)t - hi_prev;
+        hi_prev = hi;
+    }
+#ifdef GPBC_BOUNDS
+    for (int i = 0; i < NL - 1; i++) r.lb[i] = a.lb[i] + 129;       // lo in [0,2^29) never adds magnitude beyond the input's; hi within +-128
+    for (int i = 0; i < NL - 1; i++) if (r.lb[i] < 536870912.0 + 129) r.lb[i] = 536870912.0 + 129;
+    r.lb[NL - 1] = (double)P8 / 2 + 140;
+    r.vb = 0.51;
+    check_limbs(r, "fe_reduce limb");
+#endif
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------ canonical form, I/O
+// Fully reduce to [0,p) with limbs in [0,2^29) (limb 8 < 2^24). Input value must lie in (-4p, 4p).
+GPBC_INLINE Fe fe_canonical(const Fe &a) {
+    int32_t t[NL];
+    int64_t c = 0;
+    // add 4p so the value is positive while propagating carries, then subtract p while >= p (at most 8 times)
+#pragma unroll
+    for (int i = 0; i < NL - 1; i++) { int64_t s = (int64_t)a.v[i] + 4 * (int64_t)f29_p(i) + c; t[i] = (int32_t)(s & LMASK); c = s >> LB; }
+    t[NL - 1] = (int32_t)((int64_t)a.v[NL - 1] + 4 * (int64_t)f29_p(NL - 1) + c);
+    for (int rep = 0; rep < 8; rep++) {
+        int32_t d[NL];
+        int32_t b = 0;
+#pragma unroll
+        for (int i = 0; i < NL - 1; i++) { int32_t s = t[i] - f29_p(i) + b; d[i] = s & LMASK; b = s >> LB; }
+        d[NL - 1] = t[NL - 1] - f29_p(NL - 1) + b;
+        bool ge = d[NL - 1] >= 0;
+#pragma unroll
+        for (int i = 0; i < NL; i++) t[i] = ge ? d[i] : t[i];
+    }
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.v[i] = t[i];
+#ifdef GPBC_BOUNDS
+    if (a.vb >= 4.0) bounds_fail("fe_canonical input value", a.vb, 4.0);
+    set_class_n(r, 1.0);
+#endif
+    return r;
+}
+// x == 0 (mod p) for a weakly normalised x with |value| < 128p.  If x = k p then its top limb lies within |k| + 2
+// of k * p_8, so one float quotient and one integer remainder rule out all but ~2^-13 of the non-zero values; the
+// survivors take the exact (slow, divergent) path: one Montgomery product by R' mod p, canonical form, compare.
+GPBC_INLINE bool fe_is_zero(const Fe &a) {
+#ifdef GPBC_BOUNDS
+    if (a.vb >= 128.0) bounds_fail("fe_is_zero input value", a.vb, 128.0);
+    for (int i = 0; i < NL - 1; i++) if (a.lb[i] > 536870912.0 + 64) bounds_fail("fe_is_zero input limb (normalise first)", a.lb[i], 536870912.0 + 64);
+#endif
+    constexpr int32_t P8 = f29_p(NL - 1);
+    int32_t top = a.v[NL - 1];
+    int32_t k = (int32_t)rintf((float)top * (1.0f / (float)P8));
+    int32_t r = top - k * P8;
+    if (r > 136 || r < -136) return false;
+    Fe c = fe_canonical(fe_mul(a, fe_one()));
+    int32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) o |= c.v[i];
+    return o == 0;
+}
+
+// gnark fp.Element bytes (8 x u32 little-endian, Montgomery R = 2^256, canonical) <-> internal
+GPBC_INLINE Fe fe_from_words(const uint32_t w[8]) {
+    Fe x;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        int bit = LB * i, wi = bit >> 5, sh = bit & 31;
+        uint64_t two = (uint64_t)w[wi] | ((wi + 1 < 8) ? ((uint64_t)w[wi + 1] << 32) : 0);
+        x.v[i] = (int32_t)((two >> sh) & (uint64_t)LMASK);
+    }
+    GPBC_B(set_class_n(x, 1.0);)
+    constexpr int32_t C[NL] = F29_TO_INTERNAL;
+    return fe_mul(x, fe_const(C));
+}
+GPBC_INLINE void fe_to_words(uint32_t w[8], const Fe &a) {
+    constexpr int32_t C[NL] = F29_FROM_INTERNAL;
+    Fe x = fe_canonical(fe_mul(a, fe_const(C)));
+    uint64_t acc = 0;
+    int have = 0, wi = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        acc |= (uint64_t)(uint32_t)x.v[i] << have;
+        have += LB;
+        if (have >= 32 && wi < 8) { w[wi++] = (uint32_t)acc; acc >>= 32; have -= 32; }
+    }
+    if (wi < 8) w[wi] = (uint32_t)acc;
+}
+GPBC_INLINE Fe fe_load(const uint8_t *p) {
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(p);
+    uint32_t w[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = q[i];
+    return fe_from_words(w);
+}
+GPBC_INLINE void fe_store(uint8_t *p, const Fe &a) {
+    uint32_t w[8];
+    fe_to_words(w, a);
+    uint32_t *q = reinterpret_cast<uint32_t *>(p);
+#pragma unroll
+    for (int i = 0; i < 8; i++) q[i] = w[i];
+}
+GPBC_INLINE bool bytes_all_zero(const uint8_t *p, int n_words) {
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(p);
+    uint32_t o = 0;
+    for (int i = 0; i < n_words; i++) o |= q[i];
+    return o == 0;
+}
+
+// x^(p-2) (0 -> 0), plain square-and-multiply over the fixed exponent
+GPBC_NOINLINE Fe fe_inv(const Fe &x) {
+    constexpr int32_t E[NL] = F29_P;      // p - 2: subtract 2 from limb 0 (p's limb 0 is >= 2)
+    Fe r = fe_one(), b = x;
+    for (int i = 0; i < 254; i++) {
+        int limb = i / LB, bit = i % LB;
+        int32_t e = E[limb] - (limb == 0 ? 2 : 0);
+        if ((e >> bit) & 1) r = fe_mul(r, b);
+        b = fe_sqr(b);
+    }
+    return r;
+}
+
+}  // namespace gpbc
+#endif

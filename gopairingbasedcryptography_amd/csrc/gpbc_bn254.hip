@@ -1,5 +1,6 @@
 // libgpbc_bn254.so — kernels and C ABI (include/gpbc_bn254.h) of the MI355X BN254 engine.
 // gfx950 only. One batch element per lane; ABI buffers are gnark in-memory structs (AoS).
+// Arithmetic: csrc/fe29.cuh (9 x 29-bit signed limbs, lazy reduction) -> tower29 -> curve29 / pairing29.
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <cstdarg>
@@ -7,160 +8,161 @@
 #include <cstring>
 #include <vector>
 #include "../../include/gpbc_bn254.h"
-#include "curve.cuh"
-#include "pairing.cuh"
+#include "curve29.cuh"
+#include "pairing29.cuh"
 
 using namespace gpbc;
 
 // =============================================================================================== kernels
+// One batch element per lane.  Inputs/outputs are gnark structs (Montgomery R = 2^256, canonical); each kernel
+// converts to the internal 9 x 29-bit signed-limb form on load and back to canonical bytes on store.
 constexpr int BLOCK = 64;
+#ifndef GPBC_WAVES_PER_SIMD
+#define GPBC_WAVES_PER_SIMD 2
+#endif
+#define GPBC_KERNEL __global__ void __launch_bounds__(BLOCK, GPBC_WAVES_PER_SIMD)
 
-__global__ void __launch_bounds__(BLOCK) k_miller_loop(const uint8_t *__restrict__ P, const uint8_t *__restrict__ Q,
-                                                       uint8_t *__restrict__ f_out, size_t n) {
+__device__ __forceinline__ bool g1_bytes_inf(const uint8_t *p) { return bytes_all_zero(p, 16); }
+__device__ __forceinline__ bool g2_bytes_inf(const uint8_t *p) { return bytes_all_zero(p, 32); }
+
+GPBC_KERNEL k_miller_loop(const uint8_t *__restrict__ P, const uint8_t *__restrict__ Q, uint8_t *__restrict__ f_out, size_t n) {
     size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
-    G1Aff p = g1_load(P + i * GPBC_G1_BYTES);
-    G2Aff q = g2_load(Q + i * GPBC_G2_BYTES);
-    Fp12 f;
-    if (g1_is_inf(p) || g2_is_inf(q)) fp12_set_one(f);
-    else miller_loop(f, p, q);
-    fp12_store(f_out + i * GPBC_GT_BYTES, f);
+    const uint8_t *p = P + i * GPBC_G1_BYTES, *q = Q + i * GPBC_G2_BYTES;
+    F12 f;
+    if (g1_bytes_inf(p) || g2_bytes_inf(q)) f = f12_one();
+    else {
+        G1A a{fe_load(p), fe_load(p + 32)};
+        G2A b{f2_load(q), f2_load(q + 64)};
+        f = miller_loop29(a, b);
+    }
+    f12_store(f_out + i * GPBC_GT_BYTES, f);
 }
 
-__global__ void __launch_bounds__(BLOCK) k_final_exp(const uint8_t *f_in, uint8_t *gt_out, size_t n) {
+GPBC_KERNEL k_final_exp(const uint8_t *f_in, uint8_t *gt_out, size_t n) {
     size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
-    Fp12 f, z;
-    fp12_load(f, f_in + i * GPBC_GT_BYTES);
-    final_exp(z, f);
-    fp12_store(gt_out + i * GPBC_GT_BYTES, z);
+    F12 f;
+    f12_load(f, f_in + i * GPBC_GT_BYTES);
+    f12_store(gt_out + i * GPBC_GT_BYTES, final_exp29(f));
 }
 
 // product of the Miller functions of each segment: thread j multiplies f[seg_off[j] .. seg_off[j+1])
-__global__ void __launch_bounds__(BLOCK) k_segment_product(const uint8_t *__restrict__ f, const uint64_t *__restrict__ seg_off,
-                                                           uint8_t *__restrict__ out, size_t k) {
+GPBC_KERNEL k_segment_product(const uint8_t *__restrict__ f, const uint64_t *__restrict__ seg_off, uint8_t *__restrict__ out, size_t k) {
     size_t j = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (j >= k) return;
-    Fp12 acc, t;
-    fp12_set_one(acc);
+    F12 acc = f12_one(), t;
     uint64_t lo = seg_off[j], hi = seg_off[j + 1];
     for (uint64_t i = lo; i < hi; i++) {
-        fp12_load(t, f + i * GPBC_GT_BYTES);
-        if (i == lo) acc = t; else fp12_mul(acc, acc, t);
+        f12_load(t, f + i * GPBC_GT_BYTES);
+        acc = f12_mul(acc, t);
     }
-    fp12_store(out + j * GPBC_GT_BYTES, acc);
+    f12_store(out + j * GPBC_GT_BYTES, acc);
 }
 
+// GT one in gnark bytes: C0.B0.A0 = R mod p, everything else zero
 __global__ void __launch_bounds__(BLOCK) k_gt_is_one(const uint8_t *__restrict__ gt, uint8_t *__restrict__ ok, size_t n) {
     size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
-    Fp12 z;
-    fp12_load(z, gt + i * GPBC_GT_BYTES);
-    ok[i] = fp12_is_one(z) ? 1 : 0;
+    constexpr uint64_t ONE[4] = BN254_FP_ONE;
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(gt + i * GPBC_GT_BYTES);
+    uint32_t diff = 0;
+    for (int j = 0; j < 8; j++) diff |= w[j] ^ (uint32_t)(ONE[j >> 1] >> ((j & 1) * 32));
+    for (int j = 8; j < 96; j++) diff |= w[j];
+    ok[i] = diff == 0 ? 1 : 0;
 }
 
-__device__ __forceinline__ void load_scalar(u32 k[8], const uint8_t *p) {
-    const uint4 *q = reinterpret_cast<const uint4 *>(p);
-    uint4 a = q[0], b = q[1];
-    k[0] = a.x; k[1] = a.y; k[2] = a.z; k[3] = a.w; k[4] = b.x; k[5] = b.y; k[6] = b.z; k[7] = b.w;
+__device__ __forceinline__ void load_scalar(uint32_t k[8], const uint8_t *p) {
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(p);
+#pragma unroll
+    for (int i = 0; i < 8; i++) k[i] = q[i];
 }
+__device__ __forceinline__ AffP<Fe> g1_load_aff(const uint8_t *p) { return AffP<Fe>{fe_load(p), fe_load(p + 32), g1_bytes_inf(p)}; }
+__device__ __forceinline__ AffP<F2> g2_load_aff(const uint8_t *p) { return AffP<F2>{f2_load(p), f2_load(p + 64), g2_bytes_inf(p)}; }
+__device__ __forceinline__ void g1_store_aff(uint8_t *p, const AffP<Fe> &r) { fe_store(p, r.x); fe_store(p + 32, r.y); }
+__device__ __forceinline__ void g2_store_aff(uint8_t *p, const AffP<F2> &r) { f2_store(p, r.x); f2_store(p + 64, r.y); }
 
-__global__ void __launch_bounds__(BLOCK) k_g1_scalar_mul(const uint8_t *__restrict__ bases, int shared_base,
-                                                         const uint8_t *__restrict__ scalars, uint8_t *__restrict__ out, size_t n) {
+GPBC_KERNEL k_g1_scalar_mul(const uint8_t *__restrict__ bases, int shared_base, const uint8_t *__restrict__ scalars, uint8_t *__restrict__ out, size_t n) {
     size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
-    const uint8_t *bp = bases + (shared_base ? 0 : i * GPBC_G1_BYTES);
-    Aff<Fp> b{fp_load(bp), fp_load(bp + 32)}, r;
-    u32 k[8];
+    AffP<Fe> b = g1_load_aff(bases + (shared_base ? 0 : i * GPBC_G1_BYTES)), r;
+    uint32_t k[8];
     load_scalar(k, scalars + i * GPBC_SCALAR_BYTES);
-    scalar_mul<Fp>(r, b, k);
-    fp_store(out + i * GPBC_G1_BYTES, r.x);
-    fp_store(out + i * GPBC_G1_BYTES + 32, r.y);
+    scalar_mul29<Fe>(r, b, k);
+    g1_store_aff(out + i * GPBC_G1_BYTES, r);
 }
-
-__global__ void __launch_bounds__(BLOCK) k_g2_scalar_mul(const uint8_t *__restrict__ bases, int shared_base,
-                                                         const uint8_t *__restrict__ scalars, uint8_t *__restrict__ out, size_t n) {
+GPBC_KERNEL k_g2_scalar_mul(const uint8_t *__restrict__ bases, int shared_base, const uint8_t *__restrict__ scalars, uint8_t *__restrict__ out, size_t n) {
     size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
-    const uint8_t *bp = bases + (shared_base ? 0 : i * GPBC_G2_BYTES);
-    Aff<Fp2> b{fp2_load(bp), fp2_load(bp + 64)}, r;
-    u32 k[8];
+    AffP<F2> b = g2_load_aff(bases + (shared_base ? 0 : i * GPBC_G2_BYTES)), r;
+    uint32_t k[8];
     load_scalar(k, scalars + i * GPBC_SCALAR_BYTES);
-    scalar_mul<Fp2>(r, b, k);
-    fp2_store(out + i * GPBC_G2_BYTES, r.x);
-    fp2_store(out + i * GPBC_G2_BYTES + 64, r.y);
+    scalar_mul29<F2>(r, b, k);
+    g2_store_aff(out + i * GPBC_G2_BYTES, r);
 }
 
 // one level of the point-sum tree: thread t adds in[t], in[t+n_out], in[t+2 n_out], ... -> out[t] (affine)
-__global__ void __launch_bounds__(BLOCK) k_g1_sum_level(const uint8_t *__restrict__ in, size_t n_in, uint8_t *__restrict__ out, size_t n_out) {
+GPBC_KERNEL k_g1_sum_level(const uint8_t *__restrict__ in, size_t n_in, uint8_t *__restrict__ out, size_t n_out) {
     size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (t >= n_out) return;
-    Jac<Fp> acc;
+    JacP<Fe> acc;
     jac_set_inf(acc);
-    for (size_t i = t; i < n_in; i += n_out) {
-        Aff<Fp> q{fp_load(in + i * GPBC_G1_BYTES), fp_load(in + i * GPBC_G1_BYTES + 32)};
-        jac_add_mixed(acc, acc, q);
-    }
-    Aff<Fp> r;
+    for (size_t i = t; i < n_in; i += n_out) jac_add_mixed(acc, acc, g1_load_aff(in + i * GPBC_G1_BYTES));
+    AffP<Fe> r;
     jac_to_affine(r, acc);
-    fp_store(out + t * GPBC_G1_BYTES, r.x);
-    fp_store(out + t * GPBC_G1_BYTES + 32, r.y);
+    g1_store_aff(out + t * GPBC_G1_BYTES, r);
 }
-__global__ void __launch_bounds__(BLOCK) k_g2_sum_level(const uint8_t *__restrict__ in, size_t n_in, uint8_t *__restrict__ out, size_t n_out) {
+GPBC_KERNEL k_g2_sum_level(const uint8_t *__restrict__ in, size_t n_in, uint8_t *__restrict__ out, size_t n_out) {
     size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (t >= n_out) return;
-    Jac<Fp2> acc;
+    JacP<F2> acc;
     jac_set_inf(acc);
-    for (size_t i = t; i < n_in; i += n_out) {
-        Aff<Fp2> q{fp2_load(in + i * GPBC_G2_BYTES), fp2_load(in + i * GPBC_G2_BYTES + 64)};
-        jac_add_mixed(acc, acc, q);
-    }
-    Aff<Fp2> r;
+    for (size_t i = t; i < n_in; i += n_out) jac_add_mixed(acc, acc, g2_load_aff(in + i * GPBC_G2_BYTES));
+    AffP<F2> r;
     jac_to_affine(r, acc);
-    fp2_store(out + t * GPBC_G2_BYTES, r.x);
-    fp2_store(out + t * GPBC_G2_BYTES + 64, r.y);
+    g2_store_aff(out + t * GPBC_G2_BYTES, r);
 }
 
 // GT.Exp: left-to-right square-and-multiply on a 256-bit plain exponent (k = 0 -> one)
-__global__ void __launch_bounds__(BLOCK) k_gt_exp(const uint8_t *__restrict__ x, const uint8_t *__restrict__ kk, uint8_t *__restrict__ out, size_t n) {
+GPBC_KERNEL k_gt_exp(const uint8_t *__restrict__ x, const uint8_t *__restrict__ kk, uint8_t *__restrict__ out, size_t n) {
     size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
-    Fp12 b, r;
-    fp12_load(b, x + i * GPBC_GT_BYTES);
-    u32 k[8];
+    F12 b, r;
+    f12_load(b, x + i * GPBC_GT_BYTES);
+    uint32_t k[8];
     load_scalar(k, kk + i * GPBC_SCALAR_BYTES);
     int top = 255;
     while (top >= 0 && !((k[top >> 5] >> (top & 31)) & 1)) top--;
-    if (top < 0) fp12_set_one(r);
+    if (top < 0) r = f12_one();
     else {
         r = b;
         for (int j = top - 1; j >= 0; j--) {
-            fp12_sqr(r, r);
-            if ((k[j >> 5] >> (j & 31)) & 1) fp12_mul(r, r, b);
+            r = f12_sqr(r);
+            if ((k[j >> 5] >> (j & 31)) & 1) r = f12_mul(r, b);
         }
     }
-    fp12_store(out + i * GPBC_GT_BYTES, r);
+    f12_store(out + i * GPBC_GT_BYTES, r);
 }
 
 // op 0: a*b   1: a*b^-1   2: a^-1
-__global__ void __launch_bounds__(BLOCK) k_gt_binary(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, uint8_t *__restrict__ out, size_t n, int op) {
+GPBC_KERNEL k_gt_binary(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, uint8_t *__restrict__ out, size_t n, int op) {
     size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
-    Fp12 x, y, z;
-    fp12_load(x, a + i * GPBC_GT_BYTES);
-    if (op == 2) fp12_inv(z, x);
+    F12 x, y, z;
+    f12_load(x, a + i * GPBC_GT_BYTES);
+    if (op == 2) z = f12_inv(x);
     else {
-        fp12_load(y, b + i * GPBC_GT_BYTES);
-        if (op == 1) fp12_inv(y, y);
-        fp12_mul(z, x, y);
+        f12_load(y, b + i * GPBC_GT_BYTES);
+        if (op == 1) y = f12_inv(y);
+        z = f12_mul(x, y);
     }
-    fp12_store(out + i * GPBC_GT_BYTES, z);
+    f12_store(out + i * GPBC_GT_BYTES, z);
 }
 
 __global__ void __launch_bounds__(BLOCK) k_fp_mul(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, uint8_t *__restrict__ out, size_t n) {
     size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
-    fp_store(out + i * 32, fp_mul(fp_load(a + i * 32), fp_load(b + i * 32)));
+    fe_store(out + i * 32, fe_mul(fe_load(a + i * 32), fe_load(b + i * 32)));
 }
 
 // =============================================================================================== host side

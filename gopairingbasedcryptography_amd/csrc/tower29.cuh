@@ -1,0 +1,191 @@
+// Extension tower over the 29-bit-limb field (fe29.cuh); gnark E2/E6/E12 structure:
+//   F2 = Fp[i]/(i^2+1) {a0,a1};  F6 = F2[v]/(v^3-(9+i)) {b0,b1,b2};  F12 = F6[w]/(w^2-v) {c0,c1}
+// Convention: every tower function takes operands whose limbs are "N-class" (|limb| <= 2^29 + small) and returns
+// N-class results; sums and differences in between run carry-free and are re-normalised (fe_norm) only where a
+// product needs it.  F2 products are lazy: two wide column accumulations + two reductions (4 x 81 + 2 x 81 MADs)
+// instead of Karatsuba's three full multiplications — MADs cost the same as adds on this machine.
+#ifndef GPBC_TOWER29_CUH
+#define GPBC_TOWER29_CUH
+#include "fe29.cuh"
+
+namespace gpbc {
+
+struct F2 { Fe a0, a1; };
+struct F6 { F2 b0, b1, b2; };
+struct F12 { F6 c0, c1; };
+
+// ------------------------------------------------------------------------------------------- F2
+GPBC_INLINE F2 f2_zero() { return F2{fe_zero(), fe_zero()}; }
+GPBC_INLINE F2 f2_one() { return F2{fe_one(), fe_zero()}; }
+GPBC_INLINE F2 f2_add(const F2 &x, const F2 &y) { return F2{fe_add(x.a0, y.a0), fe_add(x.a1, y.a1)}; }
+GPBC_INLINE F2 f2_sub(const F2 &x, const F2 &y) { return F2{fe_sub(x.a0, y.a0), fe_sub(x.a1, y.a1)}; }
+GPBC_INLINE F2 f2_dbl(const F2 &x) { return F2{fe_dbl(x.a0), fe_dbl(x.a1)}; }
+GPBC_INLINE F2 f2_neg(const F2 &x) { return F2{fe_neg(x.a0), fe_neg(x.a1)}; }
+GPBC_INLINE F2 f2_conj(const F2 &x) { return F2{x.a0, fe_neg(x.a1)}; }
+GPBC_INLINE F2 f2_norm(const F2 &x) { return F2{fe_norm(x.a0), fe_norm(x.a1)}; }
+GPBC_INLINE F2 f2_reduce(const F2 &x) { return F2{fe_reduce(x.a0), fe_reduce(x.a1)}; }
+GPBC_INLINE F2 f2_halve(const F2 &x) { return F2{fe_halve(x.a0), fe_halve(x.a1)}; }
+GPBC_INLINE bool f2_is_zero(const F2 &x) { return fe_is_zero(x.a0) && fe_is_zero(x.a1); }
+
+GPBC_INLINE F2 f2_mul(const F2 &x, const F2 &y) {
+    return F2{fe_mul2(x.a0, y.a0, fe_neg(x.a1), y.a1), fe_mul2(x.a0, y.a1, x.a1, y.a0)};
+}
+GPBC_INLINE F2 f2_sqr(const F2 &x) {
+    return F2{fe_mul(fe_norm(fe_add(x.a0, x.a1)), fe_norm(fe_sub(x.a0, x.a1))), fe_mul(fe_dbl(x.a0), x.a1)};
+}
+GPBC_INLINE F2 f2_mul_fe(const F2 &x, const Fe &k) { return F2{fe_mul(x.a0, k), fe_mul(x.a1, k)}; }
+// (a0 + a1 i)(9 + i) = (9 a0 - a1) + (9 a1 + a0) i ; input N-class, output limbs < 3 * 2^29 (not normalised)
+GPBC_INLINE F2 f2_mul_xi(const F2 &x) {
+    return F2{fe_sub(fe_add(fe_mul8_norm(x.a0), x.a0), x.a1), fe_add(fe_add(fe_mul8_norm(x.a1), x.a1), x.a0)};
+}
+// N-class in, N-class out, and value-reduced (|value| < 0.51p): the factor |9+i| would otherwise compound
+GPBC_INLINE F2 f2_mul_xi_n(const F2 &x) {
+    F2 t = f2_norm(f2_mul_xi(x));
+    return F2{fe_reduce(t.a0), fe_reduce(t.a1)};
+}
+GPBC_INLINE F2 f2_mul8_norm(const F2 &x) { return F2{fe_mul8_norm(x.a0), fe_mul8_norm(x.a1)}; }
+GPBC_INLINE F2 f2_inv(const F2 &x) {
+    Fe n = fe_inv(fe_norm(fe_add(fe_sqr(x.a0), fe_sqr(x.a1))));
+    return F2{fe_mul(x.a0, n), fe_neg(fe_mul(x.a1, n))};
+}
+GPBC_INLINE F2 f2_load(const uint8_t *p) { return F2{fe_load(p), fe_load(p + 32)}; }
+GPBC_INLINE void f2_store(uint8_t *p, const F2 &x) { fe_store(p, x.a0); fe_store(p + 32, x.a1); }
+
+GPBC_INLINE F2 f2_const(const int32_t (&t)[2][NL]) { return F2{fe_const(t[0]), fe_const(t[1])}; }
+GPBC_INLINE F2 gamma29(int j, int k) {   // xi^(k (p^j - 1)/6), j = 1..3, k = 1..5
+    constexpr int32_t G[3][5][2][NL] = {F29_GAMMA1, F29_GAMMA2, F29_GAMMA3};
+    F2 r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) { r.a0.v[i] = G[j - 1][k - 1][0][i]; r.a1.v[i] = G[j - 1][k - 1][1][i]; }
+    GPBC_B(set_class_n(r.a0, 1.0); set_class_n(r.a1, 1.0);)
+    return r;
+}
+GPBC_INLINE F2 b_twist29() { constexpr int32_t B[2][NL] = F29_B_G2; return f2_const(B); }
+
+// ------------------------------------------------------------------------------------------- F6
+GPBC_INLINE F6 f6_add(const F6 &x, const F6 &y) { return F6{f2_add(x.b0, y.b0), f2_add(x.b1, y.b1), f2_add(x.b2, y.b2)}; }
+GPBC_INLINE F6 f6_sub(const F6 &x, const F6 &y) { return F6{f2_sub(x.b0, y.b0), f2_sub(x.b1, y.b1), f2_sub(x.b2, y.b2)}; }
+GPBC_INLINE F6 f6_neg(const F6 &x) { return F6{f2_neg(x.b0), f2_neg(x.b1), f2_neg(x.b2)}; }
+GPBC_INLINE F6 f6_norm(const F6 &x) { return F6{f2_norm(x.b0), f2_norm(x.b1), f2_norm(x.b2)}; }
+GPBC_INLINE F6 f6_reduce(const F6 &x) { return F6{f2_reduce(x.b0), f2_reduce(x.b1), f2_reduce(x.b2)}; }
+// x * v: (xi b2, b0, b1); N-class in and out
+GPBC_INLINE F6 f6_mul_v(const F6 &x) { return F6{f2_mul_xi_n(x.b2), x.b0, x.b1}; }
+
+GPBC_INLINE F6 f6_mul(const F6 &x, const F6 &y) {
+    F2 t0 = f2_mul(x.b0, y.b0), t1 = f2_mul(x.b1, y.b1), t2 = f2_mul(x.b2, y.b2);
+    F2 m12 = f2_mul(f2_norm(f2_add(x.b1, x.b2)), f2_norm(f2_add(y.b1, y.b2)));
+    F2 m01 = f2_mul(f2_norm(f2_add(x.b0, x.b1)), f2_norm(f2_add(y.b0, y.b1)));
+    F2 m02 = f2_mul(f2_norm(f2_add(x.b0, x.b2)), f2_norm(f2_add(y.b0, y.b2)));
+    F2 c0 = f2_add(f2_mul_xi_n(f2_norm(f2_sub(f2_sub(m12, t1), t2))), t0);
+    F2 c1 = f2_add(f2_norm(f2_sub(f2_sub(m01, t0), t1)), f2_mul_xi_n(t2));
+    F2 c2 = f2_add(f2_sub(f2_sub(m02, t0), t2), t1);
+    return F6{f2_norm(c0), f2_norm(c1), f2_norm(c2)};
+}
+GPBC_INLINE F6 f6_sqr(const F6 &x) {   // CH-SQR2
+    F2 s0 = f2_sqr(x.b0);
+    F2 m01 = f2_mul(x.b0, x.b1);
+    F2 s2 = f2_sqr(f2_norm(f2_add(f2_sub(x.b0, x.b1), x.b2)));
+    F2 m12 = f2_mul(x.b1, x.b2);
+    F2 s4 = f2_sqr(x.b2);
+    F2 c0 = f2_add(s0, f2_mul_xi_n(f2_norm(f2_dbl(m12))));
+    F2 c1 = f2_add(f2_dbl(m01), f2_mul_xi_n(s4));
+    F2 c2 = f2_add(f2_norm(f2_dbl(f2_add(m01, m12))), f2_norm(f2_sub(f2_sub(s2, s0), s4)));
+    return F6{f2_norm(c0), f2_norm(c1), f2_norm(c2)};
+}
+GPBC_INLINE F6 f6_mul_f2(const F6 &x, const F2 &k) { return F6{f2_mul(x.b0, k), f2_mul(x.b1, k), f2_mul(x.b2, k)}; }
+// x * (c0 + c1 v); s01 = norm(c0 + c1) supplied by the caller (shared between the two uses in the sparse F12 product)
+GPBC_INLINE F6 f6_mul_01(const F6 &x, const F2 &c0, const F2 &c1, const F2 &s01) {
+    F2 a = f2_mul(x.b0, c0), b = f2_mul(x.b1, c1);
+    F2 t0 = f2_add(f2_mul_xi_n(f2_norm(f2_sub(f2_mul(f2_norm(f2_add(x.b1, x.b2)), c1), b))), a);
+    F2 t1 = f2_sub(f2_sub(f2_mul(f2_norm(f2_add(x.b0, x.b1)), s01), a), b);
+    F2 t2 = f2_add(f2_sub(f2_mul(f2_norm(f2_add(x.b0, x.b2)), c0), a), b);
+    return F6{f2_norm(t0), f2_norm(t1), f2_norm(t2)};
+}
+GPBC_INLINE F6 f6_inv(const F6 &x) {
+    F2 t0 = f2_norm(f2_sub(f2_sqr(x.b0), f2_mul_xi_n(f2_mul(x.b1, x.b2))));
+    F2 t1 = f2_norm(f2_sub(f2_mul_xi_n(f2_sqr(x.b2)), f2_mul(x.b0, x.b1)));
+    F2 t2 = f2_norm(f2_sub(f2_sqr(x.b1), f2_mul(x.b0, x.b2)));
+    F2 inner = f2_norm(f2_add(f2_mul(x.b2, t1), f2_mul(x.b1, t2)));
+    F2 d = f2_norm(f2_add(f2_mul(x.b0, t0), f2_mul_xi_n(inner)));
+    d = f2_inv(d);
+    return F6{f2_mul(t0, d), f2_mul(t1, d), f2_mul(t2, d)};
+}
+
+// ------------------------------------------------------------------------------------------- F12
+GPBC_INLINE F12 f12_one() { return F12{F6{f2_one(), f2_zero(), f2_zero()}, F6{f2_zero(), f2_zero(), f2_zero()}}; }
+GPBC_INLINE F12 f12_conj(const F12 &x) { return F12{x.c0, f6_neg(x.c1)}; }
+GPBC_INLINE F12 f12_mul(const F12 &x, const F12 &y) {
+    F6 t0 = f6_mul(x.c0, y.c0), t1 = f6_mul(x.c1, y.c1);
+    F6 m = f6_mul(f6_norm(f6_add(x.c0, x.c1)), f6_norm(f6_add(y.c0, y.c1)));
+    F6 c1 = f6_sub(f6_sub(m, t0), t1);
+    F6 c0 = f6_add(t0, f6_mul_v(t1));
+    return F12{f6_reduce(f6_norm(c0)), f6_reduce(f6_norm(c1))};   // three-term sums of F6 products: reset the value bound
+}
+GPBC_INLINE F12 f12_sqr(const F12 &x) {
+    F6 m = f6_mul(x.c0, x.c1);
+    F6 s = f6_norm(f6_add(x.c0, x.c1));
+    F6 t = f6_norm(f6_add(x.c0, f6_mul_v(x.c1)));
+    F6 st = f6_mul(s, t);
+    F6 mv = f6_mul_v(m);
+    return F12{f6_norm(f6_sub(f6_sub(st, m), mv)), f6_norm(f6_add(m, m))};
+}
+GPBC_INLINE F12 f12_inv(const F12 &x) {
+    F6 t1 = f6_mul_v(f6_sqr(x.c1));
+    F6 d = f6_inv(f6_norm(f6_sub(f6_sqr(x.c0), t1)));
+    return F12{f6_mul(x.c0, d), f6_neg(f6_mul(x.c1, d))};
+}
+// x^(p^j), j = 1..3: coefficient of w^k -> (conj if j odd)(c_k) * gamma_j[k]; w-basis order C0.B0,C1.B0,C0.B1,C1.B1,C0.B2,C1.B2
+GPBC_INLINE F12 f12_frob(const F12 &x, int j) {
+    const bool odd = j & 1;
+    F2 c[6] = {x.c0.b0, x.c1.b0, x.c0.b1, x.c1.b1, x.c0.b2, x.c1.b2};
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        if (odd) c[k] = f2_conj(c[k]);
+        if (k) c[k] = f2_mul(c[k], gamma29(j, k));
+    }
+    return F12{F6{c[0], c[2], c[4]}, F6{c[1], c[3], c[5]}};
+}
+// Granger-Scott squaring in the cyclotomic subgroup
+GPBC_INLINE F12 f12_cyclo_sqr(const F12 &x) {
+    F2 t0 = f2_sqr(x.c1.b1), t1 = f2_sqr(x.c0.b0);
+    F2 t6 = f2_sub(f2_sub(f2_sqr(f2_norm(f2_add(x.c1.b1, x.c0.b0))), t0), t1);
+    F2 t2 = f2_sqr(x.c0.b2), t3 = f2_sqr(x.c1.b0);
+    F2 t7 = f2_sub(f2_sub(f2_sqr(f2_norm(f2_add(x.c0.b2, x.c1.b0))), t2), t3);
+    F2 t4 = f2_sqr(x.c1.b2), t5 = f2_sqr(x.c0.b1);
+    F2 t8 = f2_mul_xi_n(f2_norm(f2_sub(f2_sub(f2_sqr(f2_norm(f2_add(x.c1.b2, x.c0.b1))), t4), t5)));
+    t0 = f2_norm(f2_add(f2_mul_xi_n(t0), t1));
+    t2 = f2_norm(f2_add(f2_mul_xi_n(t2), t3));
+    t4 = f2_norm(f2_add(f2_mul_xi_n(t4), t5));
+    t6 = f2_norm(t6);
+    t7 = f2_norm(t7);
+    // 3t - 2x and 3t + 2x, each as norm(2(t -+ x)) + t.  x enters linearly, so without a value reduction the
+    // worst-case magnitude would double with every squaring of an exponentiation chain.
+    F12 r;
+    r.c0.b0 = f2_reduce(f2_norm(f2_add(f2_dbl(f2_norm(f2_sub(t0, x.c0.b0))), t0)));
+    r.c0.b1 = f2_reduce(f2_norm(f2_add(f2_dbl(f2_norm(f2_sub(t2, x.c0.b1))), t2)));
+    r.c0.b2 = f2_reduce(f2_norm(f2_add(f2_dbl(f2_norm(f2_sub(t4, x.c0.b2))), t4)));
+    r.c1.b0 = f2_reduce(f2_norm(f2_add(f2_dbl(f2_norm(f2_add(t8, x.c1.b0))), t8)));
+    r.c1.b1 = f2_reduce(f2_norm(f2_add(f2_dbl(f2_norm(f2_add(t6, x.c1.b1))), t6)));
+    r.c1.b2 = f2_reduce(f2_norm(f2_add(f2_dbl(f2_norm(f2_add(t7, x.c1.b2))), t7)));
+    return r;
+}
+// z = x * (c0 + c3 w + c4 v w): the sparse line element of the Miller loop
+GPBC_INLINE F12 f12_mul_034(const F12 &x, const F2 &c0, const F2 &c3, const F2 &c4) {
+    F2 s34 = f2_norm(f2_add(c3, c4));
+    F6 a = f6_mul_f2(x.c0, c0);
+    F6 b = f6_mul_01(x.c1, c3, c4, s34);
+    F6 r0 = f6_add(a, f6_mul_v(b));
+    F6 r1 = f6_add(f6_mul_01(x.c0, c3, c4, s34), f6_mul_f2(x.c1, c0));
+    return F12{f6_norm(r0), f6_norm(r1)};
+}
+GPBC_INLINE void f12_load(F12 &z, const uint8_t *p) {
+    z.c0.b0 = f2_load(p); z.c0.b1 = f2_load(p + 64); z.c0.b2 = f2_load(p + 128);
+    z.c1.b0 = f2_load(p + 192); z.c1.b1 = f2_load(p + 256); z.c1.b2 = f2_load(p + 320);
+}
+GPBC_INLINE void f12_store(uint8_t *p, const F12 &z) {
+    f2_store(p, z.c0.b0); f2_store(p + 64, z.c0.b1); f2_store(p + 128, z.c0.b2);
+    f2_store(p + 192, z.c1.b0); f2_store(p + 256, z.c1.b1); f2_store(p + 320, z.c1.b2);
+}
+
+}  // namespace gpbc
+#endif

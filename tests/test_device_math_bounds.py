@@ -1,0 +1,82 @@
+"""CPU verification of the DEVICE arithmetic: csrc/fe29.cuh .. pairing29.cuh compiled for the host with
+-DGPBC_BOUNDS (tools/bounds_check.cpp).  In that build every field element carries data-independent magnitude
+bounds and every Montgomery product aborts if its int64 column accumulators could overflow for ANY input, so a
+run that finishes is a proof of overflow-freedom for the straight-line code paths it exercised; the values it
+computes are the exact values the GPU computes, and are compared with the oracle bit for bit.
+(Verification harness only: the product has no CPU fallback and never loads this library.)"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import bn254_py as o
+from conftest import ROOT, cat, load_golden
+
+SO = os.path.join(ROOT, "tools", "libgpbc_bounds.so")
+
+
+@pytest.fixture(scope="module")
+def hc():
+    src = os.path.join(ROOT, "tools", "bounds_check.cpp")
+    hdrs = [os.path.join(ROOT, "gopairingbasedcryptography_amd", "csrc", f)
+            for f in ("fe29.cuh", "tower29.cuh", "curve29.cuh", "pairing29.cuh")]
+    if not os.path.exists(SO) or any(os.path.getmtime(f) > os.path.getmtime(SO) for f in [src] + hdrs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-DGPBC_BOUNDS", "-shared", "-fPIC", "-o", SO, src])
+    return ctypes.CDLL(SO)
+
+
+def vp(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def test_pairing_golden_under_bounds(hc):
+    g = load_golden("pairing.json")["cases"][:12]          # includes the infinity cases
+    P, Q = cat([c["P"] for c in g]).copy(), cat([c["Q"] for c in g]).copy()
+    out = np.zeros((len(g), 384), dtype=np.uint8)
+    hc.hc_pair(vp(P), vp(Q), ctypes.c_size_t(len(g)), vp(out))
+    for i, c in enumerate(g):
+        assert out[i].tobytes().hex() == c["GT"], c["note"]
+
+
+def test_scalar_mul_golden_under_bounds(hc):
+    for name, fn, w in (("g1_scalar_mul.json", hc.hc_g1_mul, 64), ("g2_scalar_mul.json", hc.hc_g2_mul, 128)):
+        g = load_golden(name)["cases"]
+        B, K = cat([c["base"] for c in g]).copy(), cat([c["scalar"] for c in g]).copy()
+        out = np.zeros((len(g), w), dtype=np.uint8)
+        fn(vp(B), vp(K), ctypes.c_size_t(len(g)), vp(out))
+        for i, c in enumerate(g):
+            assert out[i].tobytes().hex() == c["out"], (name, i, c["note"])
+
+
+def test_field_and_gt_ops_under_bounds(hc, oracle):
+    rng = np.random.default_rng(29)
+    n = 512
+    vals = [int.from_bytes(rng.bytes(32), "little") % o.P for _ in range(2 * n)]
+    vals[0], vals[1], vals[n], vals[n + 1] = 0, o.P - 1, o.P - 1, o.P - 1
+    a = np.frombuffer(b"".join(v.to_bytes(32, "little") for v in vals[:n]), dtype=np.uint8).copy()
+    b = np.frombuffer(b"".join(v.to_bytes(32, "little") for v in vals[n:]), dtype=np.uint8).copy()
+    out = np.zeros((n, 32), dtype=np.uint8)
+    hc.hc_fp_mul(vp(a), vp(b), ctypes.c_size_t(n), vp(out))
+    assert (out == oracle.fp_mul(a, b)).all()
+    g = load_golden("gt_ops.json")["binary"]
+    A, B = cat([c["a"] for c in g]).copy(), cat([c["b"] for c in g]).copy()
+    m = np.zeros((len(g), 384), dtype=np.uint8)
+    hc.hc_gt_mul(vp(A), vp(B), ctypes.c_size_t(len(g)), vp(m))
+    inv = np.zeros((len(g), 384), dtype=np.uint8)
+    hc.hc_gt_inv(vp(A), ctypes.c_size_t(len(g)), vp(inv))
+    sq = np.zeros((len(g), 384), dtype=np.uint8)
+    hc.hc_gt_sqr(vp(A), ctypes.c_size_t(len(g)), vp(sq), ctypes.c_int(0))
+    cs = np.zeros((len(g), 384), dtype=np.uint8)
+    hc.hc_gt_sqr(vp(A), ctypes.c_size_t(len(g)), vp(cs), ctypes.c_int(1))
+    for i, c in enumerate(g):
+        assert m[i].tobytes().hex() == c["mul"] and inv[i].tobytes().hex() == c["inv_a"]
+    assert (sq == oracle.gt_mul(A, A)).all() and (cs == sq).all()
+
+
+def test_bound_margins(hc):
+    """The worst case over everything run above stays inside int64 columns / int32 limbs."""
+    st = np.zeros(5)
+    hc.hc_stats(vp(st))
+    assert 0 < st[0] < 2.0**63 and st[1] < 2.0**31 and st[2] < 128 and st[3] > 1e5

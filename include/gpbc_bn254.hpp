@@ -1,0 +1,131 @@
+// gpbc_bn254.hpp — header-only C++ mirror of the gnark-crypto bn254 surface the reference calls, over the C ABI
+// (gpbc_bn254.h).  Same names, argument meaning and error behaviour as the Go API:
+//
+//   bn254.Pair(P []G1Affine, Q []G2Affine) (GT, error)          -> bn254::Pair(P, Q)            throws on size mismatch
+//   bn254.PairingCheck(P, Q) (bool, error)                      -> bn254::PairingCheck(P, Q)
+//   new(G1Affine).ScalarMultiplication(&a, s)                   -> G1Affine().ScalarMultiplication(a, s)
+//   new(G1Affine).ScalarMultiplicationBase(s)                   -> G1Affine().ScalarMultiplicationBase(s)
+//   new(GT).Exp(x, k) / Mul / Div / Inverse                     -> GT().Exp(x, k) ...
+//   bn254.Generators()                                          -> bn254::Generators()
+//
+// Structs have gnark's in-memory layout (fp.Element = 4 LE u64 Montgomery limbs), so arrays of them are the ABI
+// buffers.  Scalars are `Scalar` = 32-byte little-endian plain integers (what the cgo shim makes of *big.Int).
+// The Go toolchain is absent from the build image; this header is the compiled-language host side used by
+// tests/cpp/ (reference is Go, see INTEGRATION.md for the cgo shim).
+#ifndef GPBC_BN254_HPP
+#define GPBC_BN254_HPP
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "gpbc_bn254.h"
+
+namespace bn254 {
+
+struct Scalar {
+    std::array<uint8_t, 32> le{};
+    Scalar() = default;
+    explicit Scalar(uint64_t v) { for (int i = 0; i < 8; i++) le[i] = (uint8_t)(v >> (8 * i)); }
+};
+
+inline void check(int rc) { if (rc < 0) throw std::runtime_error(std::string("gpbc: ") + gpbc_last_error()); }
+inline void Init(int device = 0) { check(gpbc_init(device)); }
+
+struct fpElement { uint64_t l[4]; };
+struct E2 { fpElement A0, A1; };
+
+struct G1Affine {
+    fpElement X{}, Y{};
+    bool IsInfinity() const { uint64_t o = 0; for (int i = 0; i < 4; i++) o |= X.l[i] | Y.l[i]; return o == 0; }
+    bool Equal(const G1Affine &b) const { return std::memcmp(this, &b, sizeof *this) == 0; }
+    G1Affine &Neg(const G1Affine &a);
+    G1Affine &ScalarMultiplication(const G1Affine &a, const Scalar &s) {
+        check(gpbc_g1_scalar_mul_batch(&a, 1, s.le.data(), 1, this));
+        return *this;
+    }
+    G1Affine &ScalarMultiplicationBase(const Scalar &s);
+};
+// host-side field negation p - y on Montgomery limbs (gnark's G1Affine.Neg / G2Affine.Neg; not a hot-path operation)
+inline fpElement fpNeg(const fpElement &y) {
+    static const uint64_t P[4] = {0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+    if ((y.l[0] | y.l[1] | y.l[2] | y.l[3]) == 0) return y;
+    fpElement r;
+    unsigned __int128 b = 0;
+    for (int i = 0; i < 4; i++) {
+        unsigned __int128 d = (unsigned __int128)P[i] - y.l[i] - b;
+        r.l[i] = (uint64_t)d;
+        b = (d >> 64) & 1;
+    }
+    return r;
+}
+struct G2Affine {
+    E2 X{}, Y{};
+    bool Equal(const G2Affine &b) const { return std::memcmp(this, &b, sizeof *this) == 0; }
+    G2Affine &Neg(const G2Affine &a) { X = a.X; Y.A0 = fpNeg(a.Y.A0); Y.A1 = fpNeg(a.Y.A1); return *this; }
+    G2Affine &ScalarMultiplication(const G2Affine &a, const Scalar &s) {
+        check(gpbc_g2_scalar_mul_batch(&a, 1, s.le.data(), 1, this));
+        return *this;
+    }
+    G2Affine &ScalarMultiplicationBase(const Scalar &s);
+};
+struct GT {
+    E2 c[6]{};   // C0.B0, C0.B1, C0.B2, C1.B0, C1.B1, C1.B2
+    bool Equal(const GT &b) const { return std::memcmp(this, &b, sizeof *this) == 0; }
+    GT &Exp(const GT &x, const Scalar &k) { check(gpbc_gt_exp_batch(&x, k.le.data(), 1, this)); return *this; }
+    GT &Mul(const GT &a, const GT &b) { check(gpbc_gt_mul_batch(&a, &b, 1, this)); return *this; }
+    GT &Div(const GT &a, const GT &b) { check(gpbc_gt_div_batch(&a, &b, 1, this)); return *this; }
+    GT &Inverse(const GT &a) { check(gpbc_gt_inverse_batch(&a, 1, this)); return *this; }
+};
+static_assert(sizeof(G1Affine) == GPBC_G1_BYTES && sizeof(G2Affine) == GPBC_G2_BYTES && sizeof(GT) == GPBC_GT_BYTES, "gnark layouts");
+
+// g1 = (1, 2), g2 = the alt_bn128 twist generator, Montgomery form (tools/gen_constants.py values)
+inline void Generators(G1Affine &g1, G2Affine &g2) {
+    g1.X = {{0xd35d438dc58f0d9dULL, 0x0a78eb28f5c70b3dULL, 0x666ea36f7879462cULL, 0x0e0a77c19a07df2fULL}};
+    g1.Y = {{0xa6ba871b8b1e1b3aULL, 0x14f1d651eb8e167bULL, 0xccdd46def0f28c58ULL, 0x1c14ef83340fbe5eULL}};
+    g2.X.A0 = {{0x8e83b5d102bc2026ULL, 0xdceb1935497b0172ULL, 0xfbb8264797811adfULL, 0x19573841af96503bULL}};
+    g2.X.A1 = {{0xafb4737da84c6140ULL, 0x6043dd5a5802d8c4ULL, 0x09e950fc52a02f86ULL, 0x14fef0833aea7b6bULL}};
+    g2.Y.A0 = {{0x619dfa9d886be9f6ULL, 0xfe7fd297f59e9b78ULL, 0xff9e1a62231b7dfeULL, 0x28fd7eebae9e4206ULL}};
+    g2.Y.A1 = {{0x64095b56c71856eeULL, 0xdc57f922327d3cbbULL, 0x55f935be33351076ULL, 0x0da4a0e693fd6482ULL}};
+}
+inline G1Affine &G1Affine::Neg(const G1Affine &a) { X = a.X; Y = fpNeg(a.Y); return *this; }
+inline G1Affine &G1Affine::ScalarMultiplicationBase(const Scalar &s) { G1Affine g1; G2Affine g2; Generators(g1, g2); return ScalarMultiplication(g1, s); }
+inline G2Affine &G2Affine::ScalarMultiplicationBase(const Scalar &s) { G1Affine g1; G2Affine g2; Generators(g1, g2); return ScalarMultiplication(g2, s); }
+
+// bn254.Pair: product of pairings, one final exponentiation.  gnark's error: "invalid inputs sizes".
+inline GT Pair(const std::vector<G1Affine> &P, const std::vector<G2Affine> &Q) {
+    if (P.empty() || P.size() != Q.size()) throw std::invalid_argument("invalid inputs sizes");
+    uint64_t seg[2] = {0, P.size()};
+    GT out;
+    check(gpbc_multi_pair(P.data(), Q.data(), seg, 1, &out));
+    return out;
+}
+inline bool PairingCheck(const std::vector<G1Affine> &P, const std::vector<G2Affine> &Q) {
+    if (P.empty() || P.size() != Q.size()) throw std::invalid_argument("invalid inputs sizes");
+    uint64_t seg[2] = {0, P.size()};
+    uint8_t ok = 0;
+    check(gpbc_pairing_check(P.data(), Q.data(), seg, 1, &ok));
+    return ok == 1;
+}
+// batched forms the engine adds
+inline std::vector<GT> PairBatch(const std::vector<G1Affine> &P, const std::vector<G2Affine> &Q) {
+    if (P.empty() || P.size() != Q.size()) throw std::invalid_argument("invalid inputs sizes");
+    std::vector<GT> out(P.size());
+    check(gpbc_pair_batch(P.data(), Q.data(), P.size(), out.data()));
+    return out;
+}
+inline std::vector<G1Affine> G1ScalarMultiplicationBatch(const std::vector<G1Affine> &bases, const std::vector<Scalar> &s) {
+    std::vector<G1Affine> out(s.size());
+    check(gpbc_g1_scalar_mul_batch(bases.data(), bases.size(), s.data(), s.size(), out.data()));
+    return out;
+}
+inline std::vector<G2Affine> G2ScalarMultiplicationBatch(const std::vector<G2Affine> &bases, const std::vector<Scalar> &s) {
+    std::vector<G2Affine> out(s.size());
+    check(gpbc_g2_scalar_mul_batch(bases.data(), bases.size(), s.data(), s.size(), out.data()));
+    return out;
+}
+static_assert(sizeof(Scalar) == GPBC_SCALAR_BYTES, "scalar layout");
+
+}  // namespace bn254
+#endif

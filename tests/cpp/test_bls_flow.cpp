@@ -1,0 +1,62 @@
+// Mirrors the reference's BLS tests (signature/bls01_signature/bls_signature_test.go:8-72) on the C++ host mirror
+// of the gnark surface (include/gpbc_bn254.hpp): key generation, sign, verify through PairingCheck on the GPU,
+// plus the wrong-message / wrong-key negatives.  Hash-to-G2 is out of scope: the message point is
+// H = [h(m)]g2 with h(m) a byte-derived scalar, which keeps the sign/verify algebra of bls_signature.go:58-89.
+#include <cstdio>
+#include <string>
+#include "gpbc_bn254.hpp"
+
+using namespace bn254;
+
+static Scalar scalar_from(const std::string &s, uint64_t salt) {
+    Scalar k;
+    uint64_t h = 1469598103934665603ULL ^ salt;
+    for (int i = 0; i < 31; i++) {            // 248-bit value < r
+        for (unsigned char c : s) { h ^= c; h *= 1099511628211ULL; }
+        h ^= (uint64_t)i; h *= 1099511628211ULL;
+        k.le[i] = (uint8_t)(h >> 32);
+    }
+    return k;
+}
+struct KeyPair { G1Affine pk; Scalar sk; };
+static KeyPair KeyGenerate(uint64_t seed) {                      // bls_signature.go:38-56
+    KeyPair kp;
+    kp.sk = scalar_from("secret-key", seed);
+    kp.pk.ScalarMultiplicationBase(kp.sk);
+    return kp;
+}
+static G2Affine HashStandIn(const std::string &m) { G2Affine h; h.ScalarMultiplicationBase(scalar_from(m, 7)); return h; }
+static G2Affine Sign(const Scalar &sk, const std::string &m) {   // bls_signature.go:58-69
+    G2Affine hm = HashStandIn(m), sig;
+    sig.ScalarMultiplication(hm, sk);
+    return sig;
+}
+static bool Verify(const G1Affine &pk, const std::string &m, const G2Affine &sigma) {   // bls_signature.go:71-89
+    G1Affine g1; G2Affine g2; Generators(g1, g2);
+    G2Affine hm = HashStandIn(m), inv;
+    inv.Neg(sigma);
+    return PairingCheck({pk, g1}, {hm, inv});
+}
+#define EXPECT(c) do { if (!(c)) { printf("FAIL line %d: %s\n", __LINE__, #c); return 1; } } while (0)
+
+int main() {
+    Init(0);
+    KeyPair a = KeyGenerate(1), b = KeyGenerate(2);
+    G2Affine sig = Sign(a.sk, "hello pairing");
+    EXPECT(Verify(a.pk, "hello pairing", sig));                 // TestBLSFlow
+    EXPECT(!Verify(a.pk, "hello pairinG", sig));                // wrong message
+    EXPECT(!Verify(b.pk, "hello pairing", sig));                // wrong key
+    // bilinearity through the mirror: e([2]g1, g2) == e(g1, g2)^2 == e(g1,[2]g2)
+    G1Affine g1, g1x2; G2Affine g2, g2x2; Generators(g1, g2);
+    g1x2.ScalarMultiplication(g1, Scalar(2)); g2x2.ScalarMultiplication(g2, Scalar(2));
+    GT e = Pair({g1}, {g2}), e2 = Pair({g1x2}, {g2}), e2b = Pair({g1}, {g2x2}), sq;
+    sq.Mul(e, e);
+    EXPECT(e2.Equal(sq) && e2b.Equal(sq));
+    GT ex; ex.Exp(e, Scalar(2)); EXPECT(ex.Equal(sq));
+    GT q; q.Div(sq, e); EXPECT(q.Equal(e));
+    bool threw = false;
+    try { Pair({g1, g1}, {g2}); } catch (const std::invalid_argument &) { threw = true; }
+    EXPECT(threw);                                               // "invalid inputs sizes"
+    printf("BLS flow OK\n");
+    return 0;
+}

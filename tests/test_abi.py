@@ -68,3 +68,18 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".cuh", ".h", ".hpp", ".cpp")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle_lib" not in text and "bn254_py" not in text and "bn254_oracle" not in text, f
+
+
+def test_cpp_host_mirror_compiles_and_fails_loudly_without_gpu(lib, tmp_path):
+    """The C++ mirror of the gnark surface links against the C ABI; without a GPU it must raise, not compute."""
+    import subprocess
+    import torch
+    exe = str(tmp_path / "test_bls_flow")
+    pkg = os.path.join(ROOT, "gopairingbasedcryptography_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "test_bls_flow.cpp"),
+                           "-L" + pkg, "-lgpbc_bn254", "-Wl,-rpath," + pkg, "-o", exe])
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu-marked test")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "no CPU fallback" in out.stderr

@@ -200,3 +200,17 @@ def test_device_pointer_path(eng, synth):
     k = torch.from_numpy(scalars("s", P.shape[0]).copy()).cuda()
     assert (eng.g1_scalar_mul(dP, k).cpu().numpy() == eng.g1_scalar_mul(P, k.cpu().numpy())).all()
     assert (eng.g1_sum(dP).cpu().numpy() == eng.g1_sum(P)).all()
+
+
+def test_cpp_host_mirror_bls_flow(eng, tmp_path):
+    """include/gpbc_bn254.hpp (C++ mirror of the gnark surface) running the reference's BLS test flow on the GPU."""
+    import subprocess
+    from conftest import ROOT
+    import os
+    exe = str(tmp_path / "test_bls_flow")
+    pkg = os.path.join(ROOT, "gopairingbasedcryptography_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "test_bls_flow.cpp"),
+                           "-L" + pkg, "-lgpbc_bn254", "-Wl,-rpath," + pkg, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "BLS flow OK" in out.stdout, out.stdout + out.stderr

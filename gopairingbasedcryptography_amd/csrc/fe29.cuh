@@ -52,7 +52,7 @@ struct Fe {
 };
 
 #ifdef GPBC_BOUNDS
-struct BoundStats { double max_col = 0, max_limb = 0, max_vb = 0; long muls = 0, norms = 0; };
+struct BoundStats { double max_col = 0, max_limb = 0, max_vb = 0; long muls = 0, norms = 0, muls2 = 0, reduces = 0; };
 inline BoundStats &bound_stats() { static BoundStats s; return s; }
 inline void bounds_fail(const char *what, double got, double lim) {
     fprintf(stderr, "BOUNDS VIOLATION: %s: %.6g exceeds %.6g\n", what, got, lim);
@@ -142,8 +142,7 @@ GPBC_INLINE Fe fe_norm(const Fe &a) {
 }
 
 // ------------------------------------------------------------------------------------------------ Montgomery products
-// (a*b [+ c*d]) / 2^261 mod p.  Product scanning into 17 int64 columns (one v_mad_i64_i32 per limb pair),
-// operand-scanning reduction (m_k from column k, then 9 independent MADs), carries by one 64-bit shift per column.
+// (a*b [+ c*d]) / 2^261 mod p, one v_mad_i64_i32 per limb pair.
 // Output: limbs 0..7 in [0,2^29), limb 8 signed and small; value in (-eps p, (1+eps) p).
 template <bool TWO>
 GPBC_INLINE Fe fe_mul_core(const Fe &a, const Fe &b, const Fe &c, const Fe &d) {
@@ -164,35 +163,40 @@ GPBC_INLINE Fe fe_mul_core(const Fe &a, const Fe &b, const Fe &c, const Fe &d) {
         if (total >= 9223372036854775808.0) bounds_fail("fe_mul column", total, 9223372036854775808.0);
         if (total > bound_stats().max_col) bound_stats().max_col = total;
         bound_stats().muls++;
+        if (TWO) bound_stats().muls2++;
     }
 #endif
-    int64_t col[2 * NL - 1];
-#pragma unroll
-    for (int k = 0; k < 2 * NL - 1; k++) col[k] = 0;
-#pragma unroll
-    for (int i = 0; i < NL; i++) {
-#pragma unroll
-        for (int j = 0; j < NL; j++) {
-            col[i + j] += (int64_t)a.v[i] * (int64_t)b.v[j];
-            if (TWO) col[i + j] += (int64_t)c.v[i] * (int64_t)d.v[j];
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < NL; k++) {
-        if (k) col[k] += col[k - 1] >> LB;
-        int32_t m = (int32_t)(((uint32_t)col[k] * (uint32_t)F29_PINV) & (uint32_t)LMASK);
-#pragma unroll
-        for (int i = 0; i < NL; i++) col[k + i] += (int64_t)m * (int64_t)f29_p(i);
-    }
+    // Column-wise (product-scanning) Montgomery: one running 64-bit accumulator; column k collects its limb
+    // products and the reduction terms m_j * p_(k-j), the low columns each produce m_k and are cleared by m_k * p_0,
+    // the high columns each emit one 29-bit limb; the carry into the next column is the accumulator shifted by 29
+    // (it simply stays in the accumulator, so there is no separate carry addition).
+    int32_t m[NL];
     Fe r;
-    int64_t carry = col[NL - 1] >> LB;
+    int64_t acc = 0;
 #pragma unroll
-    for (int k = NL; k < 2 * NL - 1; k++) {
-        int64_t t = col[k] + carry;
-        r.v[k - NL] = (int32_t)(t & LMASK);
-        carry = t >> LB;
+    for (int k = 0; k < 2 * NL - 1; k++) {
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            const int j = k - i;
+            if (j < 0 || j >= NL) continue;
+            acc += (int64_t)a.v[i] * (int64_t)b.v[j];
+            if (TWO) acc += (int64_t)c.v[i] * (int64_t)d.v[j];
+        }
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            const int j = k - i;            // m_i * p_j, only for already known m_i (i < k for low columns)
+            if (j < 1 || j >= NL) continue;
+            acc += (int64_t)m[i] * (int64_t)f29_p(j);
+        }
+        if (k < NL) {
+            m[k] = (int32_t)(((uint32_t)acc * (uint32_t)F29_PINV) & (uint32_t)LMASK);
+            acc += (int64_t)m[k] * (int64_t)f29_p(0);
+        } else {
+            r.v[k - NL] = (int32_t)(acc & LMASK);
+        }
+        acc >>= LB;
     }
-    r.v[NL - 1] = (int32_t)carry;
+    r.v[NL - 1] = (int32_t)acc;
 #ifdef GPBC_BOUNDS
     double vb = (a.vb * b.vb + (TWO ? c.vb * d.vb : 0.0)) * P_OVER_RP + 1.0;
     set_class_n(r, vb);
@@ -206,7 +210,7 @@ GPBC_INLINE Fe fe_mul_core(const Fe &a, const Fe &b, const Fe &c, const Fe &d) {
 #define GPBC_PASS9(x) x.v[0], x.v[1], x.v[2], x.v[3], x.v[4], x.v[5], x.v[6], x.v[7], x.v[8]
 #define GPBC_PACK9(x) Fe{{x##0, x##1, x##2, x##3, x##4, x##5, x##6, x##7, x##8}}
 
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(GPBC_BOUNDS)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GPBC_BOUNDS) && !defined(GPBC_INLINE_LEAVES)
 // Leaf functions with every limb passed as a scalar argument: scalars go in VGPRs v0..v31 (aggregates larger than
 // 16 dwords would travel through scratch), so the tower above can stay inlined while the ~200 / ~290-instruction
 // multipliers exist once in the code object (I-cache).
@@ -290,6 +294,7 @@ GPBC_INLINE Fe fe_reduce(const Fe &a) {
     for (int i = 0; i < NL - 1; i++) if (r.lb[i] < 536870912.0 + 129) r.lb[i] = 536870912.0 + 129;
     r.lb[NL - 1] = (double)P8 / 2 + 140;
     r.vb = 0.51;
+    bound_stats().reduces++;
     check_limbs(r, "fe_reduce limb");
 #endif
     return r;

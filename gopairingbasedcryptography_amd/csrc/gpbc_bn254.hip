@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <vector>
 #include "../../include/gpbc_bn254.h"
 #include "curve29.cuh"
@@ -25,16 +26,50 @@ constexpr int BLOCK = 64;
 __device__ __forceinline__ bool g1_bytes_inf(const uint8_t *p) { return bytes_all_zero(p, 16); }
 __device__ __forceinline__ bool g2_bytes_inf(const uint8_t *p) { return bytes_all_zero(p, 32); }
 
-GPBC_KERNEL k_miller_loop(const uint8_t *__restrict__ P, const uint8_t *__restrict__ Q, uint8_t *__restrict__ f_out, size_t n) {
+// ---- Miller loop, two kernels.  The 88 lines of a pairing depend only on (P, Q), so the G2 arithmetic (phase A)
+// and the Fp12 accumulator (phase B) run as separate kernels, each with its own register budget; the lines travel
+// through an HBM workspace in internal limb form, word-major so that a wave's accesses are contiguous:
+//   lines[(step * 54 + word) * stride + lane]        (19 KB per pairing, streamed once each way)
+__device__ __forceinline__ void line_store(int32_t *__restrict__ buf, size_t stride, size_t lane, int step, const LineS &l) {
+    int32_t *b = buf + (size_t)step * LINE_WORDS * stride + lane;
+    const Fe *fe[6] = {&l.c0.a0, &l.c0.a1, &l.c3.a0, &l.c3.a1, &l.c4.a0, &l.c4.a1};
+#pragma unroll
+    for (int e = 0; e < 6; e++)
+#pragma unroll
+        for (int i = 0; i < NL; i++) b[(size_t)(e * NL + i) * stride] = fe[e]->v[i];
+}
+__device__ __forceinline__ LineS line_load(const int32_t *__restrict__ buf, size_t stride, size_t lane, int step) {
+    const int32_t *b = buf + (size_t)step * LINE_WORDS * stride + lane;
+    LineS l;
+    Fe *fe[6] = {&l.c0.a0, &l.c0.a1, &l.c3.a0, &l.c3.a1, &l.c4.a0, &l.c4.a1};
+#pragma unroll
+    for (int e = 0; e < 6; e++)
+#pragma unroll
+        for (int i = 0; i < NL; i++) fe[e]->v[i] = b[(size_t)(e * NL + i) * stride];
+    return l;
+}
+
+GPBC_KERNEL k_miller_lines(const uint8_t *__restrict__ P, const uint8_t *__restrict__ Q, int32_t *__restrict__ lines, size_t n, size_t stride) {
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t *p = P + i * GPBC_G1_BYTES, *q = Q + i * GPBC_G2_BYTES;
+    if (g1_bytes_inf(p) || g2_bytes_inf(q)) return;          // phase B skips this pair as well
+    G1A a{fe_load(p), fe_load(p + 32)};
+    G2A b{f2_load(q), f2_load(q + 64)};
+    int step = 0;
+    miller_lines(a, b, [&](const LineS &l) { line_store(lines, stride, i, step++, l); });
+}
+
+GPBC_KERNEL k_miller_accumulate(const uint8_t *__restrict__ P, const uint8_t *__restrict__ Q, const int32_t *__restrict__ lines,
+                                uint8_t *__restrict__ f_out, size_t n, size_t stride) {
     size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     const uint8_t *p = P + i * GPBC_G1_BYTES, *q = Q + i * GPBC_G2_BYTES;
     F12 f;
     if (g1_bytes_inf(p) || g2_bytes_inf(q)) f = f12_one();
     else {
-        G1A a{fe_load(p), fe_load(p + 32)};
-        G2A b{f2_load(q), f2_load(q + 64)};
-        f = miller_loop29(a, b);
+        int step = 0;
+        f = miller_accumulate([&]() -> LineS { return line_load(lines, stride, i, step++); });
     }
     f12_store(f_out + i * GPBC_GT_BYTES, f);
 }
@@ -168,6 +203,7 @@ __global__ void __launch_bounds__(BLOCK) k_fp_mul(const uint8_t *__restrict__ a,
 // =============================================================================================== host side
 static thread_local char g_err[512] = "";
 static std::atomic<int> g_device{-1};
+static void free_workspaces();
 
 static int fail(int code, const char *fmt, ...) {
     va_list ap;
@@ -239,17 +275,63 @@ int gpbc_init(int device) {
 }
 
 int gpbc_shutdown(void) {
+    free_workspaces();
     g_device.store(-1);
     return GPBC_OK;
 }
 
 // ----------------------------------------------------------------------------------------------- device-pointer API
+// Lines workspace: 88 x 54 int32 per pairing.  One grow-only buffer per (device, stream) — calls on one stream are
+// ordered, calls on different streams get different buffers — processed in chunks so the footprint stays bounded.
+constexpr size_t MILLER_CHUNK = 262144;                               // pairings per chunk: 4.98 GB of lines
+constexpr size_t LINE_BYTES_PER_PAIR = (size_t)MILLER_LINES * LINE_WORDS * sizeof(int32_t);
+struct LinesWs { int device; hipStream_t stream; void *ptr; size_t pairs; };
+static std::mutex g_ws_mu;
+static std::vector<LinesWs> g_ws;
+static int lines_workspace(hipStream_t stream, size_t pairs, int32_t **out) {
+    int dev = g_device.load();
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    for (auto &w : g_ws)
+        if (w.device == dev && w.stream == stream) {
+            if (w.pairs < pairs) {
+                HIP_TRY(hipStreamSynchronize(stream));
+                HIP_TRY(hipFree(w.ptr));
+                w.ptr = nullptr; w.pairs = 0;
+                HIP_TRY(hipMalloc(&w.ptr, pairs * LINE_BYTES_PER_PAIR));
+                w.pairs = pairs;
+            }
+            *out = (int32_t *)w.ptr;
+            return GPBC_OK;
+        }
+    void *ptr = nullptr;
+    HIP_TRY(hipMalloc(&ptr, pairs * LINE_BYTES_PER_PAIR));
+    g_ws.push_back(LinesWs{dev, stream, ptr, pairs});
+    *out = (int32_t *)ptr;
+    return GPBC_OK;
+}
+static void free_workspaces() {
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    for (auto &w : g_ws) if (w.ptr) { (void)hipSetDevice(w.device); (void)hipFree(w.ptr); }
+    g_ws.clear();
+}
+
 int gpbc_miller_loop_dev(const void *dP, const void *dQ, size_t n, void *d_f_out, void *stream) {
     if (!n) return GPBC_OK;
     if (!dP || !dQ || !d_f_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
     TRY(bind_device());
-    k_miller_loop<<<grid_for(n), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)dP, (const uint8_t *)dQ, (uint8_t *)d_f_out, n);
-    return check_launch("k_miller_loop");
+    hipStream_t st = (hipStream_t)stream;
+    size_t chunk = n < MILLER_CHUNK ? n : MILLER_CHUNK;
+    int32_t *lines = nullptr;
+    TRY(lines_workspace(st, chunk, &lines));
+    for (size_t off = 0; off < n; off += chunk) {
+        size_t m = n - off < chunk ? n - off : chunk;
+        const uint8_t *p = (const uint8_t *)dP + off * GPBC_G1_BYTES, *q = (const uint8_t *)dQ + off * GPBC_G2_BYTES;
+        k_miller_lines<<<grid_for(m), BLOCK, 0, st>>>(p, q, lines, m, chunk);
+        TRY(check_launch("k_miller_lines"));
+        k_miller_accumulate<<<grid_for(m), BLOCK, 0, st>>>(p, q, lines, (uint8_t *)d_f_out + off * GPBC_GT_BYTES, m, chunk);
+        TRY(check_launch("k_miller_accumulate"));
+    }
+    return GPBC_OK;
 }
 int gpbc_final_exp_dev(const void *d_f, size_t n, void *d_gt_out, void *stream) {
     if (!n) return GPBC_OK;

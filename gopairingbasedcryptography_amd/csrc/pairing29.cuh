@@ -54,70 +54,146 @@ GPBC_INLINE void g2_add_step(G2P &t, LineE &l, const G2A &q) {
     l.r1 = f2_neg(O);
     l.r2 = f2_norm(f2_sub(f2_mul(q.x, O), f2_mul(L, q.y)));
 }
-GPBC_INLINE F12 line_apply(const F12 &f, const LineE &l, const G1A &p) {
-    return f12_mul_034(f, f2_mul_fe(l.r0, p.y), f2_mul_fe(l.r1, p.x), l.r2);
-}
+// A Miller step's line already evaluated at P: l = c0 + c3 w + c4 v w with c0 = r0*yP, c3 = r1*xP, c4 = r2
+struct LineS { F2 c0, c3, c4; };
+constexpr int MILLER_LINES = 88;      // 65 tangent lines + 21 chords (non-zero NAF digits below the top) + 2 Frobenius chords
+constexpr int LINE_WORDS = 6 * NL;    // 54 int32 per line in internal limb form
 
-// Miller function of (p,q); caller has checked neither is infinity
-GPBC_INLINE F12 miller_loop29(const G1A &p, const G2A &q) {
-    F12 f = f12_one();
+GPBC_INLINE LineS line_scale(const LineE &l, const G1A &p) { return LineS{f2_mul_fe(l.r0, p.y), f2_mul_fe(l.r1, p.x), l.r2}; }
+
+// Phase A of the Miller loop — the G2 arithmetic.  The sequence of lines depends only on (P, Q), never on the
+// accumulator f, so it runs on its own (own kernel, own register budget) and hands the 88 lines to phase B.
+// sink(LineS) is called once per line, in evaluation order.  Caller has checked neither point is infinity.
+template <class Sink> GPBC_INLINE void miller_lines(const G1A &p, const G2A &q, Sink &&sink) {
     G2P t{q.x, q.y, f2_one()};
     G2A qn{q.x, f2_neg(q.y)};
     LineE l;
     for (int i = BN254_ATE_NAF_LEN - 2; i >= 0; i--) {
-        if (i != BN254_ATE_NAF_LEN - 2) f = f12_sqr(f);
         g2_double_step(t, l);
-        f = line_apply(f, l, p);
+        sink(line_scale(l, p));
         int d = ate_naf_digit(i);
         if (d != 0) {
             g2_add_step(t, l, d > 0 ? q : qn);
-            f = line_apply(f, l, p);
+            sink(line_scale(l, p));
         }
     }
     G2A q1{f2_mul(f2_conj(q.x), gamma29(1, 2)), f2_mul(f2_conj(q.y), gamma29(1, 3))};
     G2A q2{f2_mul(q.x, gamma29(2, 2)), f2_neg(f2_mul(q.y, gamma29(2, 3)))};
     g2_add_step(t, l, q1);
-    f = line_apply(f, l, p);
+    sink(line_scale(l, p));
     g2_add_step(t, l, q2);
-    f = line_apply(f, l, p);
+    sink(line_scale(l, p));
+}
+
+GPBC_INLINE F12 f12_from_line(const LineS &l) {
+    return F12{F6{l.c0, f2_zero(), f2_zero()}, F6{l.c3, l.c4, f2_zero()}};
+}
+// Phase B — the accumulator: f <- f^2 * l per doubling, f <- f * l per chord.  next() yields the lines in order.
+template <class Src> GPBC_INLINE F12 miller_accumulate(Src &&next) {
+    F12 f = f12_from_line(next());                 // first doubling: 1^2 * l
+    for (int i = BN254_ATE_NAF_LEN - 2; i >= 0; i--) {
+        if (i != BN254_ATE_NAF_LEN - 2) {
+            f = f12_sqr(f);
+            LineS l = next();
+            f = f12_mul_034(f, l.c0, l.c3, l.c4);
+        }
+        if (ate_naf_digit(i) != 0) {
+            LineS l = next();
+            f = f12_mul_034(f, l.c0, l.c3, l.c4);
+        }
+    }
+    for (int k = 0; k < 2; k++) {
+        LineS l = next();
+        f = f12_mul_034(f, l.c0, l.c3, l.c4);
+    }
     return f;
 }
 
-// x^u, u = 0x44e992b44a6909f1, x in the cyclotomic subgroup
-GPBC_INLINE F12 f12_expt(const F12 &x) {
-    F12 r = x;
-    for (int i = BN254_U_BITS - 2; i >= 0; i--) {
-        r = f12_cyclo_sqr(r);
-        if ((BN254_U >> i) & 1) r = f12_mul(r, x);
+// Both phases in one call (host harness; small device uses): lines staged in a local array
+GPBC_INLINE F12 miller_loop29(const G1A &p, const G2A &q) {
+    LineS lines[MILLER_LINES];
+    int n = 0;
+    miller_lines(p, q, [&](const LineS &l) { lines[n++] = l; });
+    int k = 0;
+    return miller_accumulate([&]() -> LineS { return lines[k++]; });
+}
+
+// ------------------------------------------------------------------------------------------- final exponentiation
+// F12-level steps (kept inline: measured on MI355X, staging F12 values through private memory between real function
+// calls was slower — 140 ms vs 118 ms per 2^20 final exponentiations).
+GPBC_INLINE void f12_mul_to(F12 &z, const F12 &x, const F12 &y) { z = f12_mul(x, y); }
+// n cyclotomic squarings in place; the value reduction runs on every second squaring (and always on the last)
+GPBC_INLINE void f12_cyclo_sqr_n(F12 &z, int n) {
+    F12 r = z;
+    if (n & 1) r = f12_cyclo_sqr_t<true>(r);
+    for (int i = 0; i < n / 2; i++) {
+        r = f12_cyclo_sqr_t<false>(r);
+        r = f12_cyclo_sqr_t<true>(r);
     }
-    return r;
+    z = r;
+}
+GPBC_INLINE void f12_frob_to(F12 &z, const F12 &x, int j) { z = f12_frob(x, j); }
+GPBC_INLINE void f12_inv_to(F12 &z, const F12 &x) { z = f12_inv(x); }
+
+// z = x^u, u = 0x44e992b44a6909f1, x in the cyclotomic subgroup (inverse = conjugate, free): width-4 signed windows
+// over u — 62 squarings + 13 products by x^(+-1,3,5,7) + 4 to build the table, against 27 products for the plain
+// binary method.  A real function: it is used three times by the hard part and its table lives in private memory.
+GPBC_NOINLINE void f12_expt_to(F12 &z, const F12 &x) {
+    // wNAF(u, 4), least-significant digit first (tools: sum d_i 2^i == u is asserted in tests/test_device_math_bounds.py)
+    constexpr int8_t D[GPBC_U_WNAF4_LEN] = GPBC_U_WNAF4;
+    static_assert(GPBC_U_WNAF4_LEN == 63, "digit count");
+    F12 tab[4];
+    tab[0] = x;
+    F12 x2 = f12_cyclo_sqr(x);
+    for (int k = 1; k < 4; k++) tab[k] = f12_mul(tab[k - 1], x2);
+    F12 r = tab[(D[62] - 1) / 2];                    // top digit is positive
+    int run = 0;
+    for (int i = 61; i >= 0; i--) {
+        run++;
+        int d = D[i];
+        if (d != 0) {
+            f12_cyclo_sqr_n(r, run);
+            run = 0;
+            F12 t = tab[((d < 0 ? -d : d) - 1) / 2];
+            if (d < 0) t = f12_conj(t);
+            r = f12_mul(r, t);
+        }
+    }
+    if (run) f12_cyclo_sqr_n(r, run);
+    z = r;
 }
 
 // x^(s (p^12-1)/r): easy part, then the Fuentes-Castaneda hard part (gnark's operation order).
 // gnark returns early when the easy part gives 1; the hard part maps 1 to 1, so the early exit is not needed here.
 GPBC_INLINE F12 final_exp29(const F12 &x) {
-    F12 t0 = f12_mul(f12_conj(x), f12_inv(x));
-    F12 r = f12_mul(f12_frob(t0, 2), t0);
-    t0 = f12_conj(f12_expt(r));
-    t0 = f12_cyclo_sqr(t0);
-    F12 t1 = f12_cyclo_sqr(t0);
-    t1 = f12_mul(t0, t1);
-    F12 t2 = f12_conj(f12_expt(t1));
-    F12 t3 = f12_conj(t1);
-    t1 = f12_mul(t2, t3);
-    t3 = f12_cyclo_sqr(t2);
-    F12 t4 = f12_expt(t3);
-    t4 = f12_mul(t1, t4);
-    t3 = f12_mul(t0, t4);
-    t0 = f12_mul(t2, t4);
-    t0 = f12_mul(r, t0);
-    t2 = f12_frob(t3, 1);
-    t0 = f12_mul(t2, t0);
-    t2 = f12_frob(t4, 2);
-    t0 = f12_mul(t2, t0);
-    t2 = f12_mul(f12_conj(r), t3);
-    t2 = f12_frob(t2, 3);
-    return f12_mul(t2, t0);
+    F12 r, t0, t1, t2, t3, t4;
+    f12_inv_to(t1, x);
+    t0 = f12_conj(x);
+    f12_mul_to(t0, t0, t1);
+    f12_frob_to(r, t0, 2);
+    f12_mul_to(r, r, t0);
+    f12_expt_to(t0, r); t0 = f12_conj(t0);
+    f12_cyclo_sqr_n(t0, 1);
+    t1 = t0; f12_cyclo_sqr_n(t1, 1);
+    f12_mul_to(t1, t0, t1);
+    f12_expt_to(t2, t1); t2 = f12_conj(t2);
+    t3 = f12_conj(t1);
+    f12_mul_to(t1, t2, t3);
+    t3 = t2; f12_cyclo_sqr_n(t3, 1);
+    f12_expt_to(t4, t3);
+    f12_mul_to(t4, t1, t4);
+    f12_mul_to(t3, t0, t4);
+    f12_mul_to(t0, t2, t4);
+    f12_mul_to(t0, r, t0);
+    f12_frob_to(t2, t3, 1);
+    f12_mul_to(t0, t2, t0);
+    f12_frob_to(t2, t4, 2);
+    f12_mul_to(t0, t2, t0);
+    t2 = f12_conj(r);
+    f12_mul_to(t2, t2, t3);
+    f12_frob_to(t2, t2, 3);
+    f12_mul_to(t0, t2, t0);
+    return t0;
 }
 
 }  // namespace gpbc

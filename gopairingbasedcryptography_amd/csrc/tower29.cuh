@@ -145,38 +145,46 @@ GPBC_INLINE F12 f12_frob(const F12 &x, int j) {
     }
     return F12{F6{c[0], c[2], c[4]}, F6{c[1], c[3], c[5]}};
 }
-// Granger-Scott squaring in the cyclotomic subgroup
-GPBC_INLINE F12 f12_cyclo_sqr(const F12 &x) {
+// Granger-Scott squaring in the cyclotomic subgroup.  x enters the result linearly (3t -+ 2x), so without a value
+// reduction the worst-case magnitude would double with every squaring of a chain; REDUCE = false skips it and may be
+// used for at most one squaring in a row (tools/bounds_check.cpp proves the int64 columns still cannot overflow).
+template <bool REDUCE> GPBC_INLINE F2 cyclo_out(const F2 &t, const F2 &x, bool plus) {
+    F2 d = f2_norm(plus ? f2_add(t, x) : f2_sub(t, x));
+    F2 r = f2_norm(f2_add(f2_dbl(d), t));
+    return REDUCE ? f2_reduce(r) : r;
+}
+template <bool REDUCE> GPBC_INLINE F12 f12_cyclo_sqr_t(const F12 &x) {
     F2 t0 = f2_sqr(x.c1.b1), t1 = f2_sqr(x.c0.b0);
-    F2 t6 = f2_sub(f2_sub(f2_sqr(f2_norm(f2_add(x.c1.b1, x.c0.b0))), t0), t1);
+    F2 t6 = f2_norm(f2_sub(f2_sub(f2_sqr(f2_norm(f2_add(x.c1.b1, x.c0.b0))), t0), t1));
     F2 t2 = f2_sqr(x.c0.b2), t3 = f2_sqr(x.c1.b0);
-    F2 t7 = f2_sub(f2_sub(f2_sqr(f2_norm(f2_add(x.c0.b2, x.c1.b0))), t2), t3);
+    F2 t7 = f2_norm(f2_sub(f2_sub(f2_sqr(f2_norm(f2_add(x.c0.b2, x.c1.b0))), t2), t3));
     F2 t4 = f2_sqr(x.c1.b2), t5 = f2_sqr(x.c0.b1);
     F2 t8 = f2_mul_xi_n(f2_norm(f2_sub(f2_sub(f2_sqr(f2_norm(f2_add(x.c1.b2, x.c0.b1))), t4), t5)));
     t0 = f2_norm(f2_add(f2_mul_xi_n(t0), t1));
     t2 = f2_norm(f2_add(f2_mul_xi_n(t2), t3));
     t4 = f2_norm(f2_add(f2_mul_xi_n(t4), t5));
-    t6 = f2_norm(t6);
-    t7 = f2_norm(t7);
-    // 3t - 2x and 3t + 2x, each as norm(2(t -+ x)) + t.  x enters linearly, so without a value reduction the
-    // worst-case magnitude would double with every squaring of an exponentiation chain.
     F12 r;
-    r.c0.b0 = f2_reduce(f2_norm(f2_add(f2_dbl(f2_norm(f2_sub(t0, x.c0.b0))), t0)));
-    r.c0.b1 = f2_reduce(f2_norm(f2_add(f2_dbl(f2_norm(f2_sub(t2, x.c0.b1))), t2)));
-    r.c0.b2 = f2_reduce(f2_norm(f2_add(f2_dbl(f2_norm(f2_sub(t4, x.c0.b2))), t4)));
-    r.c1.b0 = f2_reduce(f2_norm(f2_add(f2_dbl(f2_norm(f2_add(t8, x.c1.b0))), t8)));
-    r.c1.b1 = f2_reduce(f2_norm(f2_add(f2_dbl(f2_norm(f2_add(t6, x.c1.b1))), t6)));
-    r.c1.b2 = f2_reduce(f2_norm(f2_add(f2_dbl(f2_norm(f2_add(t7, x.c1.b2))), t7)));
+    r.c0.b0 = cyclo_out<REDUCE>(t0, x.c0.b0, false);
+    r.c0.b1 = cyclo_out<REDUCE>(t2, x.c0.b1, false);
+    r.c0.b2 = cyclo_out<REDUCE>(t4, x.c0.b2, false);
+    r.c1.b0 = cyclo_out<REDUCE>(t8, x.c1.b0, true);
+    r.c1.b1 = cyclo_out<REDUCE>(t6, x.c1.b1, true);
+    r.c1.b2 = cyclo_out<REDUCE>(t7, x.c1.b2, true);
     return r;
 }
-// z = x * (c0 + c3 w + c4 v w): the sparse line element of the Miller loop
+GPBC_INLINE F12 f12_cyclo_sqr(const F12 &x) { return f12_cyclo_sqr_t<true>(x); }
+// z = x * (c0 + c3 w + c4 v w): the sparse line element of the Miller loop.  Karatsuba over F6 with the sparsity
+// kept: a*l0 (3 F2 products), b*l1 (5), (a+b)*(l0+l1) (5) = 13 F2 products.
 GPBC_INLINE F12 f12_mul_034(const F12 &x, const F2 &c0, const F2 &c3, const F2 &c4) {
     F2 s34 = f2_norm(f2_add(c3, c4));
-    F6 a = f6_mul_f2(x.c0, c0);
-    F6 b = f6_mul_01(x.c1, c3, c4, s34);
-    F6 r0 = f6_add(a, f6_mul_v(b));
-    F6 r1 = f6_add(f6_mul_01(x.c0, c3, c4, s34), f6_mul_f2(x.c1, c0));
-    return F12{f6_norm(r0), f6_norm(r1)};
+    F2 c03 = f2_norm(f2_add(c0, c3));
+    F2 s034 = f2_norm(f2_add(c03, c4));
+    F6 t0 = f6_mul_f2(x.c0, c0);
+    F6 t1 = f6_mul_01(x.c1, c3, c4, s34);
+    F6 t2 = f6_mul_01(f6_norm(f6_add(x.c0, x.c1)), c03, c4, s034);
+    F6 r0 = f6_add(t0, f6_mul_v(t1));
+    F6 r1 = f6_sub(f6_sub(t2, t0), t1);
+    return F12{f6_norm(r0), f6_reduce(f6_norm(r1))};     // r1 is a three-term sum of F6 products: reset its value bound
 }
 GPBC_INLINE void f12_load(F12 &z, const uint8_t *p) {
     z.c0.b0 = f2_load(p); z.c0.b1 = f2_load(p + 64); z.c0.b2 = f2_load(p + 128);

@@ -77,6 +77,6 @@ def test_field_and_gt_ops_under_bounds(hc, oracle):
 
 def test_bound_margins(hc):
     """The worst case over everything run above stays inside int64 columns / int32 limbs."""
-    st = np.zeros(5)
+    st = np.zeros(7)
     hc.hc_stats(vp(st))
     assert 0 < st[0] < 2.0**63 and st[1] < 2.0**31 and st[2] < 128 and st[3] > 1e5

@@ -67,9 +67,10 @@ void hc_gt_inv(const uint8_t *A, size_t n, uint8_t *out) {
 void hc_gt_sqr(const uint8_t *A, size_t n, uint8_t *out, int cyclo) {
     for (size_t i = 0; i < n; i++) { F12 a; f12_load(a, A + 384 * i); f12_store(out + 384 * i, cyclo ? f12_cyclo_sqr(a) : f12_sqr(a)); }
 }
-// worst-case figures since process start: [max |int64 column|, max limb bound, max value bound (units of p), #muls, #norms]
+// worst-case figures since process start: [max |int64 column|, max limb bound, max value bound (units of p),
+// #products (fe_mul + fe_mul2), #norms, #fe_mul2, #reduces]  (out must hold 7 doubles)
 void hc_stats(double *out) {
     BoundStats &s = bound_stats();
-    out[0] = s.max_col; out[1] = s.max_limb; out[2] = s.max_vb; out[3] = (double)s.muls; out[4] = (double)s.norms;
+    out[0] = s.max_col; out[1] = s.max_limb; out[2] = s.max_vb; out[3] = (double)s.muls; out[4] = (double)s.norms; out[5] = (double)s.muls2; out[6] = (double)s.reduces;
 }
 }

@@ -1,4 +1,5 @@
 """Compile libgpbc_bn254.so for gfx950 with hipcc (in-tree, next to this file)."""
+import hashlib
 import os
 import shutil
 import subprocess
@@ -6,18 +7,27 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgpbc_bn254.so")
+STAMP = os.path.join(HERE, "libgpbc_bn254.buildhash")
 SOURCES = ["gpbc_bn254.hip"]
-HEADERS = ["fe29.cuh", "tower29.cuh", "curve29.cuh", "pairing29.cuh", "bn254_constants.cuh", "bn254_constants29.cuh"]
+HEADERS = ["fe29.cuh", "tower29.cuh", "tower29_pair.cuh", "curve29.cuh", "pairing29.cuh", "pairing29_pair.cuh", "bn254_constants.cuh", "bn254_constants29.cuh"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC"]
 
 
+def _source_hash():
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(HERE, "..", "include", "gpbc_bn254.h")]
+    for d in deps:
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def _stale():
-    if not os.path.exists(LIB):
+    """Content hash, not mtimes: the GPU box receives a copy of the tree whose timestamps are not the build's."""
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
-    deps.append(os.path.join(HERE, "..", "include", "gpbc_bn254.h"))
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(STAMP) as f:
+        return f.read().strip() != _source_hash()
 
 
 def build_library(force=False, verbose=False):
@@ -29,6 +39,8 @@ def build_library(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(_source_hash() + "\n")
     return LIB
 
 

@@ -53,7 +53,14 @@ struct Fe {
 
 #ifdef GPBC_BOUNDS
 struct BoundStats { double max_col = 0, max_limb = 0, max_vb = 0; long muls = 0, norms = 0, muls2 = 0, reduces = 0; };
-inline BoundStats &bound_stats() { static BoundStats s; return s; }
+inline BoundStats &bound_stats() { static thread_local BoundStats s; return s; }   // per thread (the pair harness runs two)
+inline void bound_stats_merge(BoundStats &into, BoundStats &from) {
+    if (from.max_col > into.max_col) into.max_col = from.max_col;
+    if (from.max_limb > into.max_limb) into.max_limb = from.max_limb;
+    if (from.max_vb > into.max_vb) into.max_vb = from.max_vb;
+    into.muls += from.muls; into.norms += from.norms; into.muls2 += from.muls2; into.reduces += from.reduces;
+    from = BoundStats();
+}
 inline void bounds_fail(const char *what, double got, double lim) {
     fprintf(stderr, "BOUNDS VIOLATION: %s: %.6g exceeds %.6g\n", what, got, lim);
     void *bt[24];

@@ -11,6 +11,7 @@
 #include "../../include/gpbc_bn254.h"
 #include "curve29.cuh"
 #include "pairing29.cuh"
+#include "pairing29_pair.cuh"
 
 using namespace gpbc;
 
@@ -60,26 +61,32 @@ GPBC_KERNEL k_miller_lines(const uint8_t *__restrict__ P, const uint8_t *__restr
     miller_lines(a, b, [&](const LineS &l) { line_store(lines, stride, i, step++, l); });
 }
 
+// Phase B and the final exponentiation run with one pairing per LANE PAIR (even lane: C0, odd lane: C1 of every Fp12
+// value, halves swapped by DPP — tower29_pair.cuh), so a batch of n pairings is a grid of 2n lanes.
 GPBC_KERNEL k_miller_accumulate(const uint8_t *__restrict__ P, const uint8_t *__restrict__ Q, const int32_t *__restrict__ lines,
                                 uint8_t *__restrict__ f_out, size_t n, size_t stride) {
-    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    size_t lane = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    size_t i = lane >> 1;
     if (i >= n) return;
+    PairDpp x{(bool)(lane & 1)};
     const uint8_t *p = P + i * GPBC_G1_BYTES, *q = Q + i * GPBC_G2_BYTES;
-    F12 f;
-    if (g1_bytes_inf(p) || g2_bytes_inf(q)) f = f12_one();
+    F6 h;
+    if (g1_bytes_inf(p) || g2_bytes_inf(q)) h = f12p_one(x);
     else {
         int step = 0;
-        f = miller_accumulate([&]() -> LineS { return line_load(lines, stride, i, step++); });
+        h = miller_accumulate_pair(x, [&]() -> LineS { return line_load(lines, stride, i, step++); });
     }
-    f12_store(f_out + i * GPBC_GT_BYTES, f);
+    f6_store(f_out + i * GPBC_GT_BYTES + (x.odd ? 192 : 0), h);
 }
 
 GPBC_KERNEL k_final_exp(const uint8_t *f_in, uint8_t *gt_out, size_t n) {
-    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    size_t lane = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    size_t i = lane >> 1;
     if (i >= n) return;
-    F12 f;
-    f12_load(f, f_in + i * GPBC_GT_BYTES);
-    f12_store(gt_out + i * GPBC_GT_BYTES, final_exp29(f));
+    PairDpp x{(bool)(lane & 1)};
+    size_t off = i * GPBC_GT_BYTES + (x.odd ? 192 : 0);
+    F6 h = f6_load(f_in + off);
+    f6_store(gt_out + off, final_exp_pair(x, h));
 }
 
 // product of the Miller functions of each segment: thread j multiplies f[seg_off[j] .. seg_off[j+1])
@@ -328,7 +335,7 @@ int gpbc_miller_loop_dev(const void *dP, const void *dQ, size_t n, void *d_f_out
         const uint8_t *p = (const uint8_t *)dP + off * GPBC_G1_BYTES, *q = (const uint8_t *)dQ + off * GPBC_G2_BYTES;
         k_miller_lines<<<grid_for(m), BLOCK, 0, st>>>(p, q, lines, m, chunk);
         TRY(check_launch("k_miller_lines"));
-        k_miller_accumulate<<<grid_for(m), BLOCK, 0, st>>>(p, q, lines, (uint8_t *)d_f_out + off * GPBC_GT_BYTES, m, chunk);
+        k_miller_accumulate<<<grid_for(2 * m), BLOCK, 0, st>>>(p, q, lines, (uint8_t *)d_f_out + off * GPBC_GT_BYTES, m, chunk);
         TRY(check_launch("k_miller_accumulate"));
     }
     return GPBC_OK;
@@ -337,7 +344,7 @@ int gpbc_final_exp_dev(const void *d_f, size_t n, void *d_gt_out, void *stream) 
     if (!n) return GPBC_OK;
     if (!d_f || !d_gt_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
     TRY(bind_device());
-    k_final_exp<<<grid_for(n), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_f, (uint8_t *)d_gt_out, n);
+    k_final_exp<<<grid_for(2 * n), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_f, (uint8_t *)d_gt_out, n);
     return check_launch("k_final_exp");
 }
 int gpbc_pair_batch_dev(const void *dP, const void *dQ, size_t n, void *d_gt_out, void *stream) {

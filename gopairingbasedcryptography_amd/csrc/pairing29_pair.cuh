@@ -1,0 +1,95 @@
+// Miller accumulator and final exponentiation with one Fp12 value per LANE PAIR (tower29_pair.cuh): even lane = C0,
+// odd lane = C1.  Same mathematics and operation order as pairing29.cuh (which remains the single-lane form used by
+// the line phase, the GT kernels and the host harness); see tower29_pair.cuh for why the state is split.
+#ifndef GPBC_PAIRING29_PAIR_CUH
+#define GPBC_PAIRING29_PAIR_CUH
+#include "pairing29.cuh"
+#include "tower29_pair.cuh"
+
+namespace gpbc {
+
+// Phase B of the Miller loop on a lane pair; next() yields the 88 lines in order (both lanes read the same line).
+template <class X, class Src> GPBC_INLINE F6 miller_accumulate_pair(const X &x, Src &&next) {
+    LineS l0 = next();
+    F6 h = f6_sel(x.odd, F6{l0.c3, l0.c4, f2_zero()}, F6{l0.c0, f2_zero(), f2_zero()});
+    for (int i = BN254_ATE_NAF_LEN - 2; i >= 0; i--) {
+        if (i != BN254_ATE_NAF_LEN - 2) {
+            h = f12p_sqr(x, h);
+            LineS l = next();
+            h = f12p_mul_034(x, h, l.c0, l.c3, l.c4);
+        }
+        if (ate_naf_digit(i) != 0) {
+            LineS l = next();
+            h = f12p_mul_034(x, h, l.c0, l.c3, l.c4);
+        }
+    }
+    for (int k = 0; k < 2; k++) {
+        LineS l = next();
+        h = f12p_mul_034(x, h, l.c0, l.c3, l.c4);
+    }
+    return h;
+}
+
+// n squarings; every one value-reduced (the lane-merged worst-case bounds leave no room to skip one, and a lane only
+// carries half of the reductions of the single-lane form anyway)
+template <class X> GPBC_INLINE F6 f12p_cyclo_sqr_n(const X &x, F6 r, int n) {
+    for (int i = 0; i < n; i++) r = f12p_cyclo_sqr<true>(x, r);
+    return r;
+}
+
+// x^u with width-4 signed windows (see f12_expt_to)
+template <class X> GPBC_NOINLINE void f12p_expt_to(const X &x, F6 &z, const F6 &b) {
+    constexpr int8_t D[GPBC_U_WNAF4_LEN] = GPBC_U_WNAF4;
+    F6 tab[4];
+    tab[0] = b;
+    F6 b2 = f12p_cyclo_sqr<true>(x, b);
+    for (int k = 1; k < 4; k++) tab[k] = f12p_mul(x, tab[k - 1], b2);
+    F6 r = tab[(D[GPBC_U_WNAF4_LEN - 1] - 1) / 2];
+    int run = 0;
+    for (int i = GPBC_U_WNAF4_LEN - 2; i >= 0; i--) {
+        run++;
+        int d = D[i];
+        if (d != 0) {
+            r = f12p_cyclo_sqr_n(x, r, run);
+            run = 0;
+            F6 t = tab[((d < 0 ? -d : d) - 1) / 2];
+            if (d < 0) t = f12p_conj(x, t);
+            r = f12p_mul(x, r, t);
+        }
+    }
+    if (run) r = f12p_cyclo_sqr_n(x, r, run);
+    z = r;
+}
+
+// x^(s (p^12-1)/r) on a lane pair; operation order of final_exp29
+template <class X> GPBC_INLINE F6 final_exp_pair(const X &x, const F6 &in) {
+    F6 r, t0, t1, t2, t3, t4;
+    t0 = f12p_mul(x, f12p_conj(x, in), f12p_inv(x, in));
+    r = f12p_mul(x, f12p_frob(x, t0, 2), t0);
+    f12p_expt_to(x, t0, r); t0 = f12p_conj(x, t0);
+    t0 = f12p_cyclo_sqr<true>(x, t0);
+    t1 = f12p_cyclo_sqr<true>(x, t0);
+    t1 = f12p_mul(x, t0, t1);
+    f12p_expt_to(x, t2, t1); t2 = f12p_conj(x, t2);
+    t3 = f12p_conj(x, t1);
+    t1 = f12p_mul(x, t2, t3);
+    t3 = f12p_cyclo_sqr<true>(x, t2);
+    f12p_expt_to(x, t4, t3);
+    t4 = f12p_mul(x, t1, t4);
+    t3 = f12p_mul(x, t0, t4);
+    t0 = f12p_mul(x, t2, t4);
+    t0 = f12p_mul(x, r, t0);
+    t2 = f12p_frob(x, t3, 1);
+    t0 = f12p_mul(x, t2, t0);
+    t2 = f12p_frob(x, t4, 2);
+    t0 = f12p_mul(x, t2, t0);
+    t2 = f12p_mul(x, f12p_conj(x, r), t3);
+    t2 = f12p_frob(x, t2, 3);
+    return f12p_mul(x, t2, t0);
+}
+
+GPBC_INLINE F6 f6_load(const uint8_t *p) { return F6{f2_load(p), f2_load(p + 64), f2_load(p + 128)}; }
+GPBC_INLINE void f6_store(uint8_t *p, const F6 &z) { f2_store(p, z.b0); f2_store(p + 64, z.b1); f2_store(p + 128, z.b2); }
+
+}  // namespace gpbc
+#endif

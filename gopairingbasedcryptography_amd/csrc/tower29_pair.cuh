@@ -1,0 +1,164 @@
+// Fp12 arithmetic with ONE Fp12 VALUE SPREAD OVER TWO ADJACENT LANES: the even lane of a pair holds C0, the odd lane
+// holds C1 (each an F6 = 54 registers).  Why: with one pairing per lane the Fp12 accumulator plus the temporaries of a
+// Karatsuba F6 product need ~350 live registers, the 256-register budget of a 2-waves-per-SIMD kernel spills ~140 KB
+// per pairing to scratch, and the kernels stall ~45 % of the time on that traffic (profiles/r01_v3_pmc_summary.txt).
+// Split over a lane pair, every F12 operation becomes one F6 product per lane with the halves swapped through DPP
+// (v_mov_b32_dpp quad_perm [1,0,3,2], full rate): the work stays balanced and the state per lane halves.
+//
+//   f12 square  (complex method)   even: m = c0*c1           odd: st = (c0+c1)(c0+v c1)      -> 6 F2 products / lane
+//   f12 * line  (034-sparse)       both: h*l0 and h*l1 on the lane's own half                 -> 8 F2 products / lane
+//   f12 * f12   (Karatsuba)        even: a0*b0 + diagonal part of the third product,
+//                                  odd:  a1*b1 + cross part of the third product              -> 9 F2 products / lane
+//   cyclotomic square              5 / 4 F2 squarings
+//
+// X is the exchange policy: X::odd (lane parity) and X::swap(F2/F6) -> the partner lane's value.  The device policy
+// uses DPP; tools/bounds_check.cpp runs the two lanes as two host threads with a rendezvous.
+#ifndef GPBC_TOWER29_PAIR_CUH
+#define GPBC_TOWER29_PAIR_CUH
+#include "tower29.cuh"
+
+namespace gpbc {
+
+GPBC_INLINE Fe fe_sel(bool c, const Fe &a, const Fe &b) {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.v[i] = c ? a.v[i] : b.v[i];
+#ifdef GPBC_BOUNDS
+    for (int i = 0; i < NL; i++) r.lb[i] = a.lb[i] > b.lb[i] ? a.lb[i] : b.lb[i];   // bound must hold for either lane
+    r.vb = a.vb > b.vb ? a.vb : b.vb;
+#endif
+    return r;
+}
+GPBC_INLINE F2 f2_sel(bool c, const F2 &a, const F2 &b) { return F2{fe_sel(c, a.a0, b.a0), fe_sel(c, a.a1, b.a1)}; }
+GPBC_INLINE F6 f6_sel(bool c, const F6 &a, const F6 &b) { return F6{f2_sel(c, a.b0, b.b0), f2_sel(c, a.b1, b.b1), f2_sel(c, a.b2, b.b2)}; }
+GPBC_INLINE F6 f6_dbl(const F6 &x) { return f6_add(x, x); }
+
+#if defined(__HIPCC__) && !defined(GPBC_BOUNDS)
+struct PairDpp {
+    bool odd;
+    __device__ __forceinline__ static int32_t sw(int32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]
+#else
+        return v;                                                      // host pass of hipcc: never executed
+#endif
+    }
+    __device__ __forceinline__ Fe swap(const Fe &a) const {
+        Fe r;
+#pragma unroll
+        for (int i = 0; i < NL; i++) r.v[i] = sw(a.v[i]);
+        return r;
+    }
+    __device__ __forceinline__ F2 swap(const F2 &a) const { return F2{swap(a.a0), swap(a.a1)}; }
+    __device__ __forceinline__ F6 swap(const F6 &a) const { return F6{swap(a.b0), swap(a.b1), swap(a.b2)}; }
+};
+#endif
+
+// (C0 on even, C1 on odd) <- one()
+template <class X> GPBC_INLINE F6 f12p_one(const X &x) { return f6_sel(x.odd, F6{f2_zero(), f2_zero(), f2_zero()}, F6{f2_one(), f2_zero(), f2_zero()}); }
+template <class X> GPBC_INLINE F6 f12p_conj(const X &x, const F6 &h) { return f6_sel(x.odd, f6_neg(h), h); }
+
+// f^2, complex method: (c0 + c1 w)^2 = (st - m - v m) + 2m w with m = c0 c1, st = (c0 + c1)(c0 + v c1)
+template <class X> GPBC_INLINE F6 f12p_sqr(const X &x, const F6 &h) {
+    F6 p = x.swap(h);
+    F6 c0 = f6_sel(x.odd, p, h), c1 = f6_sel(x.odd, h, p);
+    F6 s = f6_norm(f6_add(c0, c1));
+    F6 t = f6_norm(f6_add(c0, f6_mul_v(c1)));
+    F6 r = f6_mul(f6_sel(x.odd, s, c0), f6_sel(x.odd, t, c1));          // even: m, odd: st
+    F6 pr = x.swap(r);                                                   // even: st, odd: m
+    F6 even_out = f6_norm(f6_sub(f6_sub(pr, r), f6_mul_v(r)));
+    F6 odd_out = f6_norm(f6_dbl(pr));
+    return f6_sel(x.odd, odd_out, even_out);
+}
+
+// f * (l0 + l1 w), l0 = (c0,0,0), l1 = (c3,c4,0):  C0' = a l0 + v (b l1),  C1' = a l1 + b l0.
+// Each lane multiplies its own half by l0 and by l1 (3 + 5 F2 products), then the l1-products are swapped.
+template <class X> GPBC_INLINE F6 f12p_mul_034(const X &x, const F6 &h, const F2 &c0, const F2 &c3, const F2 &c4) {
+    F2 s34 = f2_norm(f2_add(c3, c4));
+    F6 r0 = f6_mul_f2(h, c0);
+    F6 r1 = f6_mul_01(h, c3, c4, s34);
+    F6 p1 = x.swap(r1);
+    F6 add = f6_sel(x.odd, p1, f6_mul_v(p1));
+    return f6_norm(f6_add(r0, add));
+}
+
+// full product (Karatsuba over F6).  The third product (a0+a1)(b0+b1) is itself split: the even lane computes its three
+// diagonal F2 products, the odd lane its three cross products.
+template <class X> GPBC_INLINE F6 f12p_mul(const X &x, const F6 &hx, const F6 &hy) {
+    F6 t = f6_mul(hx, hy);                                   // even: t0 = a0 b0, odd: t1 = a1 b1
+    F6 sx = f6_norm(f6_add(hx, x.swap(hx)));
+    F6 sy = f6_norm(f6_add(hy, x.swap(hy)));
+    // three F2 products per lane of sx * sy
+    F2 xa = f2_sel(x.odd, f2_norm(f2_add(sx.b1, sx.b2)), sx.b0), ya = f2_sel(x.odd, f2_norm(f2_add(sy.b1, sy.b2)), sy.b0);
+    F2 xb = f2_sel(x.odd, f2_norm(f2_add(sx.b0, sx.b1)), sx.b1), yb = f2_sel(x.odd, f2_norm(f2_add(sy.b0, sy.b1)), sy.b1);
+    F2 xc = f2_sel(x.odd, f2_norm(f2_add(sx.b0, sx.b2)), sx.b2), yc = f2_sel(x.odd, f2_norm(f2_add(sy.b0, sy.b2)), sy.b2);
+    F6 mine{f2_mul(xa, ya), f2_mul(xb, yb), f2_mul(xc, yc)};  // even: (u0,u1,u2) diagonal, odd: (m12,m01,m02) cross
+    F6 other = x.swap(mine);
+    F6 dg = f6_sel(x.odd, other, mine), cr = f6_sel(x.odd, mine, other);
+    F2 m0 = f2_add(f2_mul_xi_n(f2_norm(f2_sub(f2_sub(cr.b0, dg.b1), dg.b2))), dg.b0);
+    F2 m1 = f2_add(f2_norm(f2_sub(f2_sub(cr.b1, dg.b0), dg.b1)), f2_mul_xi_n(dg.b2));
+    F2 m2 = f2_add(f2_sub(f2_sub(cr.b2, dg.b0), dg.b2), dg.b1);
+    F6 m{f2_norm(m0), f2_norm(m1), f2_norm(m2)};              // (a0+a1)(b0+b1), on both lanes
+    F6 pt = x.swap(t);                                        // even: t1, odd: t0
+    F6 even_out = f6_add(t, f6_mul_v(pt));                    // t0 + v t1
+    F6 odd_out = f6_sub(f6_sub(m, pt), t);                    // m - t0 - t1
+    return f6_reduce(f6_norm(f6_sel(x.odd, odd_out, even_out)));
+}
+
+// Granger-Scott cyclotomic squaring.  With g_k the coefficient of w^k: even lane holds g0,g2,g4 (b0,b1,b2 of C0), odd lane
+// g1,g3,g5.  Squares needed: g0^2,g4^2? ... in tower names: t1=C0.b0^2, t0=C1.b1^2, s6=(C1.b1+C0.b0)^2, t2=C0.b2^2,
+// t3=C1.b0^2, s7=(C0.b2+C1.b0)^2, t5=C0.b1^2, t4=C1.b2^2, s8=(C1.b2+C0.b1)^2.  Even computes t1,t2,t5,s6,s7 (5), odd t0,t3,t4,s8 (4).
+template <bool REDUCE, class X> GPBC_INLINE F6 f12p_cyclo_sqr(const X &x, const F6 &h) {
+    F6 p = x.swap(h);
+    F6 c0 = f6_sel(x.odd, p, h), c1 = f6_sel(x.odd, h, p);
+    F6 own{f2_sqr(h.b0), f2_sqr(h.b1), f2_sqr(h.b2)};        // even: t1,t5,t2   odd: t3,t0,t4  (squares of own b0,b1,b2)
+    F2 sa = f2_sqr(f2_sel(x.odd, f2_norm(f2_add(c1.b2, c0.b1)), f2_norm(f2_add(c1.b1, c0.b0))));   // even: s6, odd: s8
+    F2 sb_in = f2_norm(f2_add(c0.b2, c1.b0));
+    F2 sb = f2_sqr(sb_in);                                   // s7 (the odd lane's copy is unused: 5 / 4 useful squarings)
+    F6 po = x.swap(own);
+    F2 psa = x.swap(sa), psb = x.swap(sb);
+    F2 t1 = f2_sel(x.odd, po.b0, own.b0), t5 = f2_sel(x.odd, po.b1, own.b1), t2 = f2_sel(x.odd, po.b2, own.b2);
+    F2 t3 = f2_sel(x.odd, own.b0, po.b0), t0 = f2_sel(x.odd, own.b1, po.b1), t4 = f2_sel(x.odd, own.b2, po.b2);
+    F2 s6 = f2_sel(x.odd, psa, sa), s8 = f2_sel(x.odd, sa, psa), s7 = f2_sel(x.odd, psb, sb);
+    // even lane outputs (C0):  3(xi t0 + t1) - 2 c0.b0,  3(xi t2 + t3) - 2 c0.b1,  3(xi t4 + t5) - 2 c0.b2
+    // odd lane outputs  (C1):  3 xi (s8-t4-t5) + 2 c1.b0,  3 (s6-t0-t1) + 2 c1.b1,  3 (s7-t2-t3) + 2 c1.b2
+    F2 e0 = f2_norm(f2_add(f2_mul_xi_n(t0), t1)), e1 = f2_norm(f2_add(f2_mul_xi_n(t2), t3)), e2 = f2_norm(f2_add(f2_mul_xi_n(t4), t5));
+    F2 o0 = f2_mul_xi_n(f2_norm(f2_sub(f2_sub(s8, t4), t5)));
+    F2 o1 = f2_norm(f2_sub(f2_sub(s6, t0), t1)), o2 = f2_norm(f2_sub(f2_sub(s7, t2), t3));
+    F2 tt0 = f2_sel(x.odd, o0, e0), tt1 = f2_sel(x.odd, o1, e1), tt2 = f2_sel(x.odd, o2, e2);
+    // out = 3 tt -+ 2 own coefficient  (minus on the even lane, plus on the odd lane)
+    F6 sgn = f6_sel(x.odd, h, f6_neg(h));
+    F6 r{f2_norm(f2_add(f2_dbl(f2_norm(f2_add(tt0, sgn.b0))), tt0)),
+         f2_norm(f2_add(f2_dbl(f2_norm(f2_add(tt1, sgn.b1))), tt1)),
+         f2_norm(f2_add(f2_dbl(f2_norm(f2_add(tt2, sgn.b2))), tt2))};
+    return REDUCE ? f6_reduce(r) : r;
+}
+
+// x^(p^j): coefficient of w^k -> (conj if j odd)(g_k) * gamma_j[k]; even lane k = 0,2,4, odd lane k = 1,3,5
+template <class X> GPBC_INLINE F6 f12p_frob(const X &x, const F6 &h, int j) {
+    const bool cj = j & 1;
+    F2 g[3] = {h.b0, h.b1, h.b2};
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        if (cj) g[i] = f2_conj(g[i]);
+        // even: k = 2i (gamma index 2i, none for i = 0); odd: k = 2i+1
+        F2 ge = i ? gamma29(j, 2 * i) : f2_one();
+        F2 go = gamma29(j, 2 * i + 1);
+        F2 prod = f2_mul(g[i], f2_sel(x.odd, go, ge));
+        g[i] = (i == 0) ? f2_sel(x.odd, prod, g[i]) : prod;
+    }
+    return F6{g[0], g[1], g[2]};
+}
+
+// 1 / (c0 + c1 w) = (c0 - c1 w) / (c0^2 - v c1^2)
+template <class X> GPBC_INLINE F6 f12p_inv(const X &x, const F6 &h) {
+    F6 s = f6_sqr(h);                                         // even: c0^2, odd: c1^2
+    F6 ps = x.swap(s);
+    F6 a = f6_sel(x.odd, ps, s), b = f6_sel(x.odd, s, ps);
+    F6 d = f6_inv(f6_norm(f6_sub(a, f6_mul_v(b))));          // both lanes (redundant, once per final exponentiation)
+    F6 r = f6_mul(h, d);
+    return f6_sel(x.odd, f6_neg(r), r);
+}
+
+}  // namespace gpbc
+#endif

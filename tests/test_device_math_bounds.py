@@ -21,9 +21,9 @@ SO = os.path.join(ROOT, "tools", "libgpbc_bounds.so")
 def hc():
     src = os.path.join(ROOT, "tools", "bounds_check.cpp")
     hdrs = [os.path.join(ROOT, "gopairingbasedcryptography_amd", "csrc", f)
-            for f in ("fe29.cuh", "tower29.cuh", "curve29.cuh", "pairing29.cuh")]
+            for f in ("fe29.cuh", "tower29.cuh", "tower29_pair.cuh", "curve29.cuh", "pairing29.cuh", "pairing29_pair.cuh")]
     if not os.path.exists(SO) or any(os.path.getmtime(f) > os.path.getmtime(SO) for f in [src] + hdrs):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-DGPBC_BOUNDS", "-shared", "-fPIC", "-o", SO, src])
+        subprocess.check_call(["g++", "-O2", "-pthread", "-std=c++17", "-DGPBC_BOUNDS", "-shared", "-fPIC", "-o", SO, src])
     return ctypes.CDLL(SO)
 
 
@@ -80,3 +80,37 @@ def test_bound_margins(hc):
     st = np.zeros(7)
     hc.hc_stats(vp(st))
     assert 0 < st[0] < 2.0**63 and st[1] < 2.0**31 and st[2] < 128 and st[3] > 1e5
+
+
+def test_lane_pair_forms_under_bounds(hc, oracle):
+    """tower29_pair.cuh / pairing29_pair.cuh: one Fp12 value per lane pair (two host threads + rendezvous stand in for
+    the DPP swap).  Every pair-form operation and the full pair-form pairing must match the oracle bit for bit."""
+    n = 3
+    g1 = np.frombuffer(o.g1_to_bytes(o.G1_GEN), dtype=np.uint8)
+    g2 = np.frombuffer(o.g2_to_bytes(o.G2_GEN), dtype=np.uint8)
+    k = np.frombuffer(b"".join(o.scalar_to_bytes(o.bench_scalar("P", 40 + i)) for i in range(n)), dtype=np.uint8).copy()
+    P, Q = oracle.g1_scalar_mul(g1, k), oracle.g2_scalar_mul(g2, k)
+    ref = oracle.pair_batch(P, Q)
+    A, B = ref.copy(), np.roll(ref, 1, axis=0).copy()
+    outs = [np.zeros((n, 384), dtype=np.uint8) for _ in range(5)]
+    hc.hc_gt_pair_ops(vp(A), vp(B), ctypes.c_size_t(n), *[vp(x) for x in outs])
+    assert (outs[0] == oracle.gt_mul(A, B)).all()
+    assert (outs[1] == oracle.gt_mul(A, A)).all() and (outs[2] == outs[1]).all()
+    assert (outs[3] == oracle.gt_inverse(A)).all()
+    frob = np.frombuffer(b"".join(o.gt_to_bytes(o.f12_frobenius(o.gt_from_bytes(A[i].tobytes()))) for i in range(n)),
+                         dtype=np.uint8).reshape(n, 384)
+    assert (outs[4] == frob).all()
+    f = np.zeros((n, 384), dtype=np.uint8)
+    hc.hc_pair_lanes(vp(P), vp(Q), ctypes.c_size_t(n), vp(f), ctypes.c_int(0))
+    assert (oracle.final_exp(f) == ref).all()
+    gt = np.zeros((n, 384), dtype=np.uint8)
+    hc.hc_pair_lanes(vp(P), vp(Q), ctypes.c_size_t(n), vp(gt), ctypes.c_int(1))
+    assert (gt == ref).all()
+
+
+def test_wnaf_digits_of_u():
+    import re
+    from conftest import ROOT
+    text = open(os.path.join(ROOT, "gopairingbasedcryptography_amd", "csrc", "bn254_constants.cuh")).read()
+    digits = [int(x) for x in re.search(r"#define GPBC_U_WNAF4 \{([^}]*)\}", text).group(1).split(",")]
+    assert sum(d << i for i, d in enumerate(digits)) == o.U and all(d == 0 or (d % 2 and abs(d) < 8) for d in digits)

@@ -10,8 +10,39 @@
 #include <cstring>
 #include "../gopairingbasedcryptography_amd/csrc/curve29.cuh"
 #include "../gopairingbasedcryptography_amd/csrc/pairing29.cuh"
+#include "../gopairingbasedcryptography_amd/csrc/pairing29_pair.cuh"
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 
 using namespace gpbc;
+
+// Host stand-in for the DPP lane swap: the two lanes of a pair run as two threads; swap() is a rendezvous.
+struct PairRendezvous {
+    std::mutex mu; std::condition_variable cv;
+    const void *slot[2] = {nullptr, nullptr}; int arrived = 0, left = 0; long gen = 0;
+    template <class T> T exchange(int me, const T &v) {
+        std::unique_lock<std::mutex> lk(mu);
+        while (left != 0) cv.wait(lk);                 // previous exchange fully drained
+        slot[me] = &v;
+        long g = gen;
+        if (++arrived == 2) { gen++; left = 2; cv.notify_all(); }
+        else while (gen == g) cv.wait(lk);
+        T out = *static_cast<const T *>(slot[1 - me]);
+        if (--left == 0) { arrived = 0; cv.notify_all(); }
+        else while (left != 0) cv.wait(lk);            // keep my value alive until the partner has copied it
+        return out;
+    }
+};
+struct PairHost {
+    bool odd; PairRendezvous *rv;
+    Fe swap(const Fe &a) const { return rv->exchange<Fe>(odd, a); }
+    F2 swap(const F2 &a) const { return rv->exchange<F2>(odd, a); }
+    F6 swap(const F6 &a) const { return rv->exchange<F6>(odd, a); }
+};
+static std::mutex g_stats_mu;
+static BoundStats g_stats_total;
+static void stats_flush() { std::lock_guard<std::mutex> lk(g_stats_mu); bound_stats_merge(g_stats_total, bound_stats()); }
 
 extern "C" {
 
@@ -67,10 +98,53 @@ void hc_gt_inv(const uint8_t *A, size_t n, uint8_t *out) {
 void hc_gt_sqr(const uint8_t *A, size_t n, uint8_t *out, int cyclo) {
     for (size_t i = 0; i < n; i++) { F12 a; f12_load(a, A + 384 * i); f12_store(out + 384 * i, cyclo ? f12_cyclo_sqr(a) : f12_sqr(a)); }
 }
+// pair-lane forms: Miller accumulator fed by the single-lane line phase, and the final exponentiation
+void hc_pair_lanes(const uint8_t *P, const uint8_t *Q, size_t n, uint8_t *out, int do_final_exp) {
+    for (size_t i = 0; i < n; i++) {
+        const uint8_t *p = P + 64 * i, *q = Q + 128 * i;
+        G1A a{fe_load(p), fe_load(p + 32)};
+        G2A b{f2_load(q), f2_load(q + 64)};
+        LineS lines[MILLER_LINES];
+        int cnt = 0;
+        miller_lines(a, b, [&](const LineS &l) { lines[cnt++] = l; });
+        PairRendezvous rv;
+        auto lane = [&](bool odd) {
+            PairHost x{odd, &rv};
+            int k = 0;
+            F6 h = miller_accumulate_pair(x, [&]() -> LineS { return lines[k++]; });
+            if (do_final_exp) h = final_exp_pair(x, h);
+            f6_store(out + 384 * i + (odd ? 192 : 0), h);
+            stats_flush();
+        };
+        std::thread t1(lane, true);
+        lane(false);
+        t1.join();
+    }
+}
+void hc_gt_pair_ops(const uint8_t *A, const uint8_t *B, size_t n, uint8_t *mul, uint8_t *sqr, uint8_t *csqr, uint8_t *inv, uint8_t *frob1) {
+    for (size_t i = 0; i < n; i++) {
+        PairRendezvous rv;
+        auto lane = [&](bool odd) {
+            PairHost x{odd, &rv};
+            size_t o = 384 * i + (odd ? 192 : 0);
+            F6 a = f6_load(A + o), b = f6_load(B + o);
+            f6_store(mul + o, f12p_mul(x, a, b));
+            f6_store(sqr + o, f12p_sqr(x, a));
+            f6_store(csqr + o, f12p_cyclo_sqr<true>(x, a));
+            f6_store(inv + o, f12p_inv(x, a));
+            f6_store(frob1 + o, f12p_frob(x, a, 1));
+            stats_flush();
+        };
+        std::thread t1(lane, true);
+        lane(false);
+        t1.join();
+    }
+}
 // worst-case figures since process start: [max |int64 column|, max limb bound, max value bound (units of p),
 // #products (fe_mul + fe_mul2), #norms, #fe_mul2, #reduces]  (out must hold 7 doubles)
 void hc_stats(double *out) {
-    BoundStats &s = bound_stats();
+    stats_flush();
+    BoundStats &s = g_stats_total;
     out[0] = s.max_col; out[1] = s.max_limb; out[2] = s.max_vb; out[3] = (double)s.muls; out[4] = (double)s.norms; out[5] = (double)s.muls2; out[6] = (double)s.reduces;
 }
 }

@@ -214,3 +214,38 @@ def test_cpp_host_mirror_bls_flow(eng, tmp_path):
                            "-L" + pkg, "-lgpbc_bn254", "-Wl,-rpath," + pkg, "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "BLS flow OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_large_batch_chunks_and_properties(eng, oracle):
+    """BASELINE size (2^20 would take the oracle ~1 min on one core, so 2^18 + 5 pairs here: more than one lines-workspace
+    chunk of 262144, ragged tail): HBM-resident path, spot-checked against the oracle at chunk boundaries, plus
+    size-independent properties over the whole batch: e(P,Q)*e(-P,Q) == 1 per element through multi_pair, and
+    e([2]P,Q) == e(P,Q)^2 as a checksum of all outputs."""
+    import torch
+    n = (1 << 18) + 5
+    g1, g2 = eng.generators()
+    rng = np.random.default_rng(20)
+    k = np.frombuffer(rng.bytes(32 * n), dtype=np.uint8).copy().reshape(n, 32)
+    k[:, 31] &= 0x1F                                            # < 2^253 < r
+    dk = torch.from_numpy(k).cuda()
+    dP = eng.g1_scalar_mul(torch.from_numpy(g1).cuda(), dk)
+    dQ = eng.g2_scalar_mul(torch.from_numpy(g2).cuda(), dk.flip(0).contiguous())
+    gt = eng.pair_batch(dP, dQ)
+    torch.cuda.synchronize()
+    idx = np.array([0, 1, 63, 64, 262143, 262144, 262145, n - 2, n - 1, 131071, 200000])
+    P, Q, G = dP[idx].cpu().numpy(), dQ[idx].cpu().numpy(), gt[idx].cpu().numpy()
+    assert (G == oracle.pair_batch(P, Q, threads=8)).all()
+    # e([2]P, Q) == e(P,Q)^2 for every element (GPU-only identity over the full batch)
+    two = torch.from_numpy(np.tile(np.frombuffer((2).to_bytes(32, "little"), dtype=np.uint8), n).reshape(n, 32).copy()).cuda()
+    gt2 = eng.pair_batch(eng.g1_scalar_mul(dP, two), dQ)
+    sq = eng.gt_mul(gt, gt)
+    assert bool((gt2 == sq).all())
+    # product with the negated point is one: multi_pair with 2-pair segments
+    m = 4096
+    negP = dP[:m].cpu().numpy().copy()
+    for i in range(m):
+        negP[i] = np.frombuffer(o.g1_to_bytes(o.g1_neg(o.g1_from_bytes(negP[i].tobytes()))), dtype=np.uint8)
+    PP = np.stack([dP[:m].cpu().numpy(), negP], axis=1).reshape(-1, 64)
+    QQ = np.repeat(dQ[:m].cpu().numpy(), 2, axis=0)
+    ok = eng.pairing_check_batch(PP, QQ, np.arange(0, 2 * m + 1, 2))
+    assert ok.all()

@@ -26,11 +26,11 @@ GPBC_INLINE void g2_double_step(G2P &t, LineE &l) {
     F2 E = f2_mul(f2_norm(f2_add(f2_dbl(C), C)), b_twist29());
     F2 F = f2_add(f2_dbl(E), E);
     F2 G = f2_halve(f2_norm(f2_add(B, F)));
-    F2 H = f2_sub(f2_sqr(f2_norm(f2_add(t.y, t.z))), f2_add(B, C));
+    F2 H = f2_sub(f2_sqr_n(f2_add(t.y, t.z)), f2_add(B, C));
     F2 J = f2_sqr(t.x);
     F2 EE = f2_sqr(E);
     t.x = f2_mul(f2_norm(A), f2_norm(f2_sub(B, F)));
-    t.y = f2_norm(f2_sub(f2_sqr(f2_norm(G)), f2_add(f2_dbl(EE), EE)));
+    t.y = f2_norm(f2_sub(f2_sqr_n(G), f2_add(f2_dbl(EE), EE)));
     t.z = f2_mul(B, f2_norm(H));
     l.r0 = f2_norm(f2_neg(H));
     l.r1 = f2_norm(f2_add(f2_dbl(J), J));

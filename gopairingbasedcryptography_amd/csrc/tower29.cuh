@@ -27,12 +27,50 @@ GPBC_INLINE F2 f2_reduce(const F2 &x) { return F2{fe_reduce(x.a0), fe_reduce(x.a
 GPBC_INLINE F2 f2_halve(const F2 &x) { return F2{fe_halve(x.a0), fe_halve(x.a1)}; }
 GPBC_INLINE bool f2_is_zero(const F2 &x) { return fe_is_zero(x.a0) && fe_is_zero(x.a1); }
 
-GPBC_INLINE F2 f2_mul(const F2 &x, const F2 &y) {
-    return F2{fe_mul2(x.a0, y.a0, fe_neg(x.a1), y.a1), fe_mul2(x.a0, y.a1, x.a1, y.a0)};
+// Lazy schoolbook product and complex squaring.  NORM variants first re-normalise their operands (used for the sums
+// of the Karatsuba layers above), so that the normalisation code lives inside the leaf instead of at every call site.
+template <bool NORM> GPBC_INLINE F2 f2_mul_core(const F2 &xx, const F2 &yy) {
+    F2 x = NORM ? f2_norm(xx) : xx, y = NORM ? f2_norm(yy) : yy;
+    return F2{fe_mul_core<true>(x.a0, y.a0, fe_neg(x.a1), y.a1), fe_mul_core<true>(x.a0, y.a1, x.a1, y.a0)};
 }
-GPBC_INLINE F2 f2_sqr(const F2 &x) {
-    return F2{fe_mul(fe_norm(fe_add(x.a0, x.a1)), fe_norm(fe_sub(x.a0, x.a1))), fe_mul(fe_dbl(x.a0), x.a1)};
+template <bool NORM> GPBC_INLINE F2 f2_sqr_core(const F2 &xx) {
+    F2 x = NORM ? f2_norm(xx) : xx;
+    return F2{fe_mul_core<false>(fe_norm(fe_add(x.a0, x.a1)), fe_norm(fe_sub(x.a0, x.a1)), x.a0, x.a0),
+              fe_mul_core<false>(fe_dbl(x.a0), x.a1, x.a0, x.a0)};
 }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GPBC_BOUNDS) && !defined(GPBC_INLINE_LEAVES)
+// F2-level leaves: one call per F2 product / squaring, all 36 / 18 limbs as scalar arguments (VGPRs; the last few of
+// the 36 travel through the stack), the 18 result limbs returned in registers as one vector value.
+typedef int32_t i32x18 __attribute__((ext_vector_type(18)));
+#define GPBC_PACK_F2(a, b) F2{GPBC_PACK9(a), GPBC_PACK9(b)}
+GPBC_INLINE i32x18 f2_to_vec(const F2 &r) {
+    i32x18 v;
+#pragma unroll
+    for (int i = 0; i < NL; i++) { v[i] = r.a0.v[i]; v[NL + i] = r.a1.v[i]; }
+    return v;
+}
+GPBC_INLINE F2 f2_from_vec(const i32x18 &v) {
+    F2 r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) { r.a0.v[i] = v[i]; r.a1.v[i] = v[NL + i]; }
+    return r;
+}
+template <bool NORM> __device__ __noinline__ i32x18 f2_mul_leaf(GPBC_ARGS9(a), GPBC_ARGS9(b), GPBC_ARGS9(c), GPBC_ARGS9(d)) {
+    return f2_to_vec(f2_mul_core<NORM>(GPBC_PACK_F2(a, b), GPBC_PACK_F2(c, d)));
+}
+template <bool NORM> __device__ __noinline__ i32x18 f2_sqr_leaf(GPBC_ARGS9(a), GPBC_ARGS9(b)) {
+    return f2_to_vec(f2_sqr_core<NORM>(GPBC_PACK_F2(a, b)));
+}
+GPBC_INLINE F2 f2_mul(const F2 &x, const F2 &y) { return f2_from_vec(f2_mul_leaf<false>(GPBC_PASS9(x.a0), GPBC_PASS9(x.a1), GPBC_PASS9(y.a0), GPBC_PASS9(y.a1))); }
+GPBC_INLINE F2 f2_mul_nn(const F2 &x, const F2 &y) { return f2_from_vec(f2_mul_leaf<true>(GPBC_PASS9(x.a0), GPBC_PASS9(x.a1), GPBC_PASS9(y.a0), GPBC_PASS9(y.a1))); }
+GPBC_INLINE F2 f2_sqr(const F2 &x) { return f2_from_vec(f2_sqr_leaf<false>(GPBC_PASS9(x.a0), GPBC_PASS9(x.a1))); }
+GPBC_INLINE F2 f2_sqr_n(const F2 &x) { return f2_from_vec(f2_sqr_leaf<true>(GPBC_PASS9(x.a0), GPBC_PASS9(x.a1))); }
+#else
+GPBC_INLINE F2 f2_mul(const F2 &x, const F2 &y) { return f2_mul_core<false>(x, y); }
+GPBC_INLINE F2 f2_mul_nn(const F2 &x, const F2 &y) { return f2_mul_core<true>(x, y); }      // both operands un-normalised sums
+GPBC_INLINE F2 f2_sqr(const F2 &x) { return f2_sqr_core<false>(x); }
+GPBC_INLINE F2 f2_sqr_n(const F2 &x) { return f2_sqr_core<true>(x); }                        // operand an un-normalised sum
+#endif
 GPBC_INLINE F2 f2_mul_fe(const F2 &x, const Fe &k) { return F2{fe_mul(x.a0, k), fe_mul(x.a1, k)}; }
 // (a0 + a1 i)(9 + i) = (9 a0 - a1) + (9 a1 + a0) i ; input N-class, output limbs < 3 * 2^29 (not normalised)
 GPBC_INLINE F2 f2_mul_xi(const F2 &x) {
@@ -73,9 +111,9 @@ GPBC_INLINE F6 f6_mul_v(const F6 &x) { return F6{f2_mul_xi_n(x.b2), x.b0, x.b1};
 
 GPBC_INLINE F6 f6_mul(const F6 &x, const F6 &y) {
     F2 t0 = f2_mul(x.b0, y.b0), t1 = f2_mul(x.b1, y.b1), t2 = f2_mul(x.b2, y.b2);
-    F2 m12 = f2_mul(f2_norm(f2_add(x.b1, x.b2)), f2_norm(f2_add(y.b1, y.b2)));
-    F2 m01 = f2_mul(f2_norm(f2_add(x.b0, x.b1)), f2_norm(f2_add(y.b0, y.b1)));
-    F2 m02 = f2_mul(f2_norm(f2_add(x.b0, x.b2)), f2_norm(f2_add(y.b0, y.b2)));
+    F2 m12 = f2_mul_nn(f2_add(x.b1, x.b2), f2_add(y.b1, y.b2));
+    F2 m01 = f2_mul_nn(f2_add(x.b0, x.b1), f2_add(y.b0, y.b1));
+    F2 m02 = f2_mul_nn(f2_add(x.b0, x.b2), f2_add(y.b0, y.b2));
     F2 c0 = f2_add(f2_mul_xi_n(f2_norm(f2_sub(f2_sub(m12, t1), t2))), t0);
     F2 c1 = f2_add(f2_norm(f2_sub(f2_sub(m01, t0), t1)), f2_mul_xi_n(t2));
     F2 c2 = f2_add(f2_sub(f2_sub(m02, t0), t2), t1);
@@ -84,7 +122,7 @@ GPBC_INLINE F6 f6_mul(const F6 &x, const F6 &y) {
 GPBC_INLINE F6 f6_sqr(const F6 &x) {   // CH-SQR2
     F2 s0 = f2_sqr(x.b0);
     F2 m01 = f2_mul(x.b0, x.b1);
-    F2 s2 = f2_sqr(f2_norm(f2_add(f2_sub(x.b0, x.b1), x.b2)));
+    F2 s2 = f2_sqr_n(f2_add(f2_sub(x.b0, x.b1), x.b2));
     F2 m12 = f2_mul(x.b1, x.b2);
     F2 s4 = f2_sqr(x.b2);
     F2 c0 = f2_add(s0, f2_mul_xi_n(f2_norm(f2_dbl(m12))));
@@ -155,11 +193,11 @@ template <bool REDUCE> GPBC_INLINE F2 cyclo_out(const F2 &t, const F2 &x, bool p
 }
 template <bool REDUCE> GPBC_INLINE F12 f12_cyclo_sqr_t(const F12 &x) {
     F2 t0 = f2_sqr(x.c1.b1), t1 = f2_sqr(x.c0.b0);
-    F2 t6 = f2_norm(f2_sub(f2_sub(f2_sqr(f2_norm(f2_add(x.c1.b1, x.c0.b0))), t0), t1));
+    F2 t6 = f2_norm(f2_sub(f2_sub(f2_sqr_n(f2_add(x.c1.b1, x.c0.b0)), t0), t1));
     F2 t2 = f2_sqr(x.c0.b2), t3 = f2_sqr(x.c1.b0);
-    F2 t7 = f2_norm(f2_sub(f2_sub(f2_sqr(f2_norm(f2_add(x.c0.b2, x.c1.b0))), t2), t3));
+    F2 t7 = f2_norm(f2_sub(f2_sub(f2_sqr_n(f2_add(x.c0.b2, x.c1.b0)), t2), t3));
     F2 t4 = f2_sqr(x.c1.b2), t5 = f2_sqr(x.c0.b1);
-    F2 t8 = f2_mul_xi_n(f2_norm(f2_sub(f2_sub(f2_sqr(f2_norm(f2_add(x.c1.b2, x.c0.b1))), t4), t5)));
+    F2 t8 = f2_mul_xi_n(f2_norm(f2_sub(f2_sub(f2_sqr_n(f2_add(x.c1.b2, x.c0.b1)), t4), t5)));
     t0 = f2_norm(f2_add(f2_mul_xi_n(t0), t1));
     t2 = f2_norm(f2_add(f2_mul_xi_n(t2), t3));
     t4 = f2_norm(f2_add(f2_mul_xi_n(t4), t5));

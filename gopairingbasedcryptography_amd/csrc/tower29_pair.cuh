@@ -61,10 +61,10 @@ template <class X> GPBC_INLINE F6 f12p_conj(const X &x, const F6 &h) { return f6
 // f^2, complex method: (c0 + c1 w)^2 = (st - m - v m) + 2m w with m = c0 c1, st = (c0 + c1)(c0 + v c1)
 template <class X> GPBC_INLINE F6 f12p_sqr(const X &x, const F6 &h) {
     F6 p = x.swap(h);
-    F6 c0 = f6_sel(x.odd, p, h), c1 = f6_sel(x.odd, h, p);
-    F6 s = f6_norm(f6_add(c0, c1));
-    F6 t = f6_norm(f6_add(c0, f6_mul_v(c1)));
-    F6 r = f6_mul(f6_sel(x.odd, s, c0), f6_sel(x.odd, t, c1));          // even: m, odd: st
+    // even lane (h = c0, p = c1): m = h * p.   odd lane (h = c1, p = c0): st = (h + p) * (p + v h).
+    F6 s = f6_norm(f6_add(h, p));
+    F6 t = f6_norm(f6_add(p, f6_mul_v(h)));
+    F6 r = f6_mul(f6_sel(x.odd, s, h), f6_sel(x.odd, t, p));            // even: m, odd: st
     F6 pr = x.swap(r);                                                   // even: st, odd: m
     F6 even_out = f6_norm(f6_sub(f6_sub(pr, r), f6_mul_v(r)));
     F6 odd_out = f6_norm(f6_dbl(pr));

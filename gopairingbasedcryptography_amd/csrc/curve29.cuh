@@ -87,15 +87,99 @@ template <class F> GPBC_INLINE void jac_to_affine(AffP<F> &r, const JacP<F> &p) 
     r.inf = false;
 }
 
-// [k]base, k = 256-bit little-endian plain integer (8 x u32). Left-to-right binary double-and-add.
+// ------------------------------------------------------------------------------------------- GLV scalar decomposition
+// BN254 has j = 0: phi(x, y) = (beta x, y) is an endomorphism acting as [lambda] on the order-r groups (G1 with
+// beta1, the twist subgroup G2 with beta2 = beta1^2; tools/gen_constants.py derives and checks the constants).  A scalar
+// splits as k = k1 + k2*lambda (mod r) with |k1|, |k2| < 2^130, halving the doublings of [k]P = [k1]P + [k2]phi(P).
+// (gnark-crypto's ScalarMultiplication uses the same endomorphism; the affine result is the unique point [k mod r]P.)
+//   c1 = (k * g1) >> 256,  c2 = (k * g2) >> 256     (g1 ~ 2^256 b2 / r, g2 ~ 2^256 |b1| / r; any rounding error only
+//   k1 = k - c1*a1 - c2*a2,  k2 = c1*|b1| - c2*b2     widens k1, k2 by a few bits: the identity holds exactly)
+struct GlvSplit { uint32_t k1[5], k2[5]; bool neg1, neg2; };
+
+template <int NA, int NB, int NO> GPBC_INLINE void mp_mul(uint32_t (&out)[NO], const uint32_t (&a)[NA], const uint32_t (&b)[NB]) {
+    // out = low NO limbs of a * b
+    uint64_t col[NO + 1];
+#pragma unroll
+    for (int i = 0; i <= NO; i++) col[i] = 0;
+    uint64_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < NO; k++) {
+        uint64_t lo = carry, hi = 0;
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            const int j = k - i;
+            if (j < 0 || j >= NB) continue;
+            uint64_t p = (uint64_t)a[i] * (uint64_t)b[j];
+            lo += p & 0xffffffffu;
+            hi += p >> 32;
+        }
+        out[k] = (uint32_t)lo;
+        carry = (lo >> 32) + hi;
+    }
+    (void)col;
+}
+template <int N> GPBC_INLINE void mp_sub(uint32_t (&r)[N], const uint32_t (&a)[N], const uint32_t (&b)[N]) {
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        uint64_t d = (uint64_t)a[i] - b[i] - borrow;
+        r[i] = (uint32_t)d;
+        borrow = (d >> 32) & 1;
+    }
+}
+GPBC_INLINE void glv_split(GlvSplit &o, const uint32_t kin[8]) {
+    constexpr uint32_t R32[8] = GLV_R32, G1[3] = GLV_G1, G2[5] = GLV_G2, A1[2] = GLV_A1, A2[4] = GLV_A2, B1[4] = GLV_B1ABS, B2[2] = GLV_B2;
+    uint32_t k[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) k[i] = kin[i];
+    for (int rep = 0; rep < 6; rep++) {            // k < 2^256 < 6r: reduce to [0, r)
+        uint32_t d[8];
+        uint64_t borrow = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { uint64_t t = (uint64_t)k[i] - R32[i] - borrow; d[i] = (uint32_t)t; borrow = (t >> 32) & 1; }
+#pragma unroll
+        for (int i = 0; i < 8; i++) k[i] = borrow ? k[i] : d[i];
+    }
+    uint32_t p1[11], p2[13];
+    mp_mul<8, 3, 11>(p1, k, G1);
+    mp_mul<8, 5, 13>(p2, k, G2);
+    uint32_t c1[3] = {p1[8], p1[9], p1[10]}, c2[5] = {p2[8], p2[9], p2[10], p2[11], p2[12]};
+    uint32_t t1[5], t2[5], t3[5], t4[5], k5[5] = {k[0], k[1], k[2], k[3], k[4]}, r1[5], r2[5];
+    mp_mul<3, 2, 5>(t1, c1, A1);
+    mp_mul<5, 4, 5>(t2, c2, A2);
+    mp_sub<5>(r1, k5, t1);
+    mp_sub<5>(r1, r1, t2);                           // k1 mod 2^160 (two's complement)
+    mp_mul<3, 4, 5>(t3, c1, B1);
+    mp_mul<5, 2, 5>(t4, c2, B2);
+    mp_sub<5>(r2, t3, t4);                           // k2 mod 2^160
+    o.neg1 = (r1[4] >> 31) != 0;
+    o.neg2 = (r2[4] >> 31) != 0;
+    uint32_t zero[5] = {0, 0, 0, 0, 0}, n1[5], n2[5];
+    mp_sub<5>(n1, zero, r1);
+    mp_sub<5>(n2, zero, r2);
+#pragma unroll
+    for (int i = 0; i < 5; i++) { o.k1[i] = o.neg1 ? n1[i] : r1[i]; o.k2[i] = o.neg2 ? n2[i] : r2[i]; }
+}
+
+GPBC_INLINE Fe glv_phi_x(const Fe &x) { constexpr int32_t B[NL] = GLV_BETA_G1; return fe_mul(x, fe_const(B)); }
+GPBC_INLINE F2 glv_phi_x(const F2 &x) { constexpr int32_t B[NL] = GLV_BETA_G2; return f2_mul_fe(x, fe_const(B)); }
+GPBC_INLINE Fe g_neg(const Fe &a) { return fe_neg(a); }
+GPBC_INLINE F2 g_neg(const F2 &a) { return f2_neg(a); }
+
+// [k]base for any 256-bit k: interleaved double-and-add over the two ~128-bit halves of the GLV split
 template <class F> GPBC_INLINE void scalar_mul29(AffP<F> &out, const AffP<F> &base, const uint32_t k[8]) {
+    GlvSplit s;
+    glv_split(s, k);
+    AffP<F> p1{base.x, s.neg1 ? g_neg(base.y) : base.y, base.inf};
+    AffP<F> p2{glv_phi_x(base.x), s.neg2 ? g_neg(base.y) : base.y, base.inf};
     JacP<F> acc;
     jac_set_inf(acc);
-    int top = 255;
-    while (top >= 0 && !((k[top >> 5] >> (top & 31)) & 1)) top--;
+    int top = 159;
+    while (top >= 0 && !(((s.k1[top >> 5] | s.k2[top >> 5]) >> (top & 31)) & 1)) top--;
     for (int i = top; i >= 0; i--) {
         jac_dbl(acc, acc);
-        if ((k[i >> 5] >> (i & 31)) & 1) jac_add_mixed(acc, acc, base);
+        if ((s.k1[i >> 5] >> (i & 31)) & 1) jac_add_mixed(acc, acc, p1);
+        if ((s.k2[i >> 5] >> (i & 31)) & 1) jac_add_mixed(acc, acc, p2);
     }
     jac_to_affine(out, acc);
 }

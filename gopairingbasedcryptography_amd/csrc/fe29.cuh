@@ -237,7 +237,65 @@ GPBC_INLINE Fe fe_mul2(const Fe &a, const Fe &b, const Fe &c, const Fe &d) {
 GPBC_INLINE Fe fe_mul(const Fe &a, const Fe &b) { return fe_mul_core<false>(a, b, a, b); }
 GPBC_INLINE Fe fe_mul2(const Fe &a, const Fe &b, const Fe &c, const Fe &d) { return fe_mul_core<true>(a, b, c, d); }
 #endif
-GPBC_INLINE Fe fe_sqr(const Fe &a) { return fe_mul(a, a); }
+// a^2 / 2^261 mod p with the symmetric half of the product only: column k = sum_{i<j, i+j=k} (2 a_i) a_j + a_(k/2)^2,
+// 45 product MADs instead of 81 (the reduction half is unchanged).
+GPBC_INLINE Fe fe_sqr_core(const Fe &a) {
+#ifdef GPBC_BOUNDS
+    {
+        double worst = 0;
+        for (int k = 0; k < 2 * NL - 1; k++) {
+            double s = 0;
+            for (int i = 0; i < NL; i++) { int j = k - i; if (j >= 0 && j < NL) s += a.lb[i] * a.lb[j]; }
+            if (s > worst) worst = s;
+        }
+        double total = worst + 9.0 * 536870912.0 * 536870912.0 + 34359738368.0;
+        if (total >= 9223372036854775808.0) bounds_fail("fe_sqr column", total, 9223372036854775808.0);
+        for (int i = 0; i < NL; i++) if (2 * a.lb[i] >= 2147483648.0) bounds_fail("fe_sqr doubled limb", 2 * a.lb[i], 2147483648.0);
+        if (total > bound_stats().max_col) bound_stats().max_col = total;
+        bound_stats().muls++;
+    }
+#endif
+    int32_t d[NL], m[NL];
+#pragma unroll
+    for (int i = 0; i < NL; i++) d[i] = a.v[i] * 2;
+    Fe r;
+    int64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * NL - 1; k++) {
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            const int j = k - i;
+            if (j < 0 || j >= NL || i > j) continue;
+            acc += (i == j) ? (int64_t)a.v[i] * (int64_t)a.v[i] : (int64_t)d[i] * (int64_t)a.v[j];
+        }
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            const int j = k - i;
+            if (j < 1 || j >= NL) continue;
+            acc += (int64_t)m[i] * (int64_t)f29_p(j);
+        }
+        if (k < NL) {
+            m[k] = (int32_t)(((uint32_t)acc * (uint32_t)F29_PINV) & (uint32_t)LMASK);
+            acc += (int64_t)m[k] * (int64_t)f29_p(0);
+        } else {
+            r.v[k - NL] = (int32_t)(acc & LMASK);
+        }
+        acc >>= LB;
+    }
+    r.v[NL - 1] = (int32_t)acc;
+#ifdef GPBC_BOUNDS
+    set_class_n(r, a.vb * a.vb * P_OVER_RP + 1.0);
+    if (r.lb[NL - 1] >= 268435456.0) bounds_fail("fe_sqr output top limb", r.lb[NL - 1], 268435456.0);
+    check_limbs(r, "fe_sqr output");
+#endif
+    return r;
+}
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GPBC_BOUNDS) && !defined(GPBC_INLINE_LEAVES)
+__device__ __noinline__ Fe fe_sqr_leaf(GPBC_ARGS9(a)) { Fe a = GPBC_PACK9(a); return fe_sqr_core(a); }
+GPBC_INLINE Fe fe_sqr(const Fe &a) { return fe_sqr_leaf(GPBC_PASS9(a)); }
+#else
+GPBC_INLINE Fe fe_sqr(const Fe &a) { return fe_sqr_core(a); }
+#endif
 
 // ------------------------------------------------------------------------------------------------ small multiples
 // 8a with the limbs re-split on the fly (no limb grows beyond 2^29 + 2^(k+3) for |a limbs| < 2^(29+k))

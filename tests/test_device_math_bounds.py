@@ -114,3 +114,21 @@ def test_wnaf_digits_of_u():
     text = open(os.path.join(ROOT, "gopairingbasedcryptography_amd", "csrc", "bn254_constants.cuh")).read()
     digits = [int(x) for x in re.search(r"#define GPBC_U_WNAF4 \{([^}]*)\}", text).group(1).split(",")]
     assert sum(d << i for i, d in enumerate(digits)) == o.U and all(d == 0 or (d % 2 and abs(d) < 8) for d in digits)
+
+
+def test_glv_split_identity(hc):
+    """k == k1 + k2*lambda (mod r) with |k1|,|k2| < 2^130 for edge and random 256-bit scalars (curve29.cuh glv_split)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_constants as gc
+    lam = gc.glv_constants()[0]
+    rng = np.random.default_rng(5)
+    ks = [0, 1, 2, o.R - 1, o.R, o.R + 5, (1 << 256) - 1, 1 << 255, lam, lam + 1, o.R - lam] + \
+         [int.from_bytes(rng.bytes(32), "little") for _ in range(300)]
+    K = np.frombuffer(b"".join(k.to_bytes(32, "little") for k in ks), dtype=np.uint8).copy()
+    out = np.zeros((len(ks), 12), dtype=np.uint32)
+    hc.hc_glv_split(vp(K), ctypes.c_size_t(len(ks)), vp(out))
+    for k, row in zip(ks, out):
+        k1 = sum(int(row[i]) << (32 * i) for i in range(5)) * (-1 if row[10] else 1)
+        k2 = sum(int(row[5 + i]) << (32 * i) for i in range(5)) * (-1 if row[11] else 1)
+        assert (k1 + k2 * lam - k) % o.R == 0 and abs(k1).bit_length() <= 130 and abs(k2).bit_length() <= 130

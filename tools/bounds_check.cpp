@@ -85,6 +85,15 @@ void hc_g2_mul(const uint8_t *B, const uint8_t *K, size_t n, uint8_t *out) {
         f2_store(out + 128 * i, r.x); f2_store(out + 128 * i + 64, r.y);
     }
 }
+// GLV split of n 256-bit scalars: out rows = [k1 (5 x u32), k2 (5 x u32), neg1, neg2] as 12 u32
+void hc_glv_split(const uint8_t *K, size_t n, uint32_t *out) {
+    for (size_t i = 0; i < n; i++) {
+        uint32_t k[8]; memcpy(k, K + 32 * i, 32);
+        GlvSplit s; glv_split(s, k);
+        memcpy(out + 12 * i, s.k1, 20); memcpy(out + 12 * i + 5, s.k2, 20);
+        out[12 * i + 10] = s.neg1; out[12 * i + 11] = s.neg2;
+    }
+}
 void hc_fp_mul(const uint8_t *A, const uint8_t *B, size_t n, uint8_t *out) {
     // gnark-form a (= x R) and b (= y R), R = 2^256: internal product of the converted operands is x y R' -> stored as x y R
     for (size_t i = 0; i < n; i++) fe_store(out + 32 * i, fe_mul(fe_load(A + 32 * i), fe_load(B + 32 * i)));

@@ -95,37 +95,36 @@ template <class X> GPBC_INLINE F6 f12p_mul(const X &x, const F6 &hx, const F6 &h
     F6 mine{f2_mul(xa, ya), f2_mul(xb, yb), f2_mul(xc, yc)};  // even: (u0,u1,u2) diagonal, odd: (m12,m01,m02) cross
     F6 other = x.swap(mine);
     F6 dg = f6_sel(x.odd, other, mine), cr = f6_sel(x.odd, mine, other);
-    F2 m0 = f2_add(f2_mul_xi_n(f2_norm(f2_sub(f2_sub(cr.b0, dg.b1), dg.b2))), dg.b0);
+    F6 pt = x.swap(t);                                        // even: t1, odd: t0
+    // one shared xi-multiplication: the odd lane needs xi (m12 - u1 - u2) for m, the even lane xi t1.b2 for v t1
+    F2 xi1 = f2_mul_xi_n(f2_sel(x.odd, f2_norm(f2_sub(f2_sub(cr.b0, dg.b1), dg.b2)), pt.b2));
+    F2 m0 = f2_add(xi1, dg.b0);
     F2 m1 = f2_add(f2_norm(f2_sub(f2_sub(cr.b1, dg.b0), dg.b1)), f2_mul_xi_n(dg.b2));
     F2 m2 = f2_add(f2_sub(f2_sub(cr.b2, dg.b0), dg.b2), dg.b1);
-    F6 m{f2_norm(m0), f2_norm(m1), f2_norm(m2)};              // (a0+a1)(b0+b1), on both lanes
-    F6 pt = x.swap(t);                                        // even: t1, odd: t0
-    F6 even_out = f6_add(t, f6_mul_v(pt));                    // t0 + v t1
+    F6 m{f2_norm(m0), f2_norm(m1), f2_norm(m2)};              // (a0+a1)(b0+b1): meaningful on the odd lane
+    F6 even_out = f6_add(t, F6{xi1, pt.b0, pt.b1});           // t0 + v t1
     F6 odd_out = f6_sub(f6_sub(m, pt), t);                    // m - t0 - t1
     return f6_reduce(f6_norm(f6_sel(x.odd, odd_out, even_out)));
 }
 
-// Granger-Scott cyclotomic squaring.  With g_k the coefficient of w^k: even lane holds g0,g2,g4 (b0,b1,b2 of C0), odd lane
-// g1,g3,g5.  Squares needed: g0^2,g4^2? ... in tower names: t1=C0.b0^2, t0=C1.b1^2, s6=(C1.b1+C0.b0)^2, t2=C0.b2^2,
-// t3=C1.b0^2, s7=(C0.b2+C1.b0)^2, t5=C0.b1^2, t4=C1.b2^2, s8=(C1.b2+C0.b1)^2.  Even computes t1,t2,t5,s6,s7 (5), odd t0,t3,t4,s8 (4).
+// Granger-Scott cyclotomic squaring.  In tower names the nine squarings are t1=C0.b0^2, t5=C0.b1^2, t2=C0.b2^2,
+// t3=C1.b0^2, t0=C1.b1^2, t4=C1.b2^2, s6=(C0.b0+C1.b1)^2, s7=(C0.b2+C1.b0)^2, s8=(C1.b2+C0.b1)^2 and the result is
+//   C0' = 3(xi t0 + t1) - 2 C0.b0,  3(xi t2 + t3) - 2 C0.b1,  3(xi t4 + t5) - 2 C0.b2
+//   C1' = 3 xi (s8-t4-t5) + 2 C1.b0,  3 (s6-t0-t1) + 2 C1.b1,  3 (s7-t2-t3) + 2 C1.b2.
+// Each lane squares its own three coefficients and one or two of the mixed sums (5 / 4 squarings), and the four
+// multiplications by xi are shared two per lane: the even lane forms xi t2 and xi (s8-t4-t5), the odd lane xi t4, xi t0.
 template <bool REDUCE, class X> GPBC_INLINE F6 f12p_cyclo_sqr(const X &x, const F6 &h) {
     F6 p = x.swap(h);
-    F6 c0 = f6_sel(x.odd, p, h), c1 = f6_sel(x.odd, h, p);
-    F6 own{f2_sqr(h.b0), f2_sqr(h.b1), f2_sqr(h.b2)};        // even: t1,t5,t2   odd: t3,t0,t4  (squares of own b0,b1,b2)
-    F2 sa = f2_sqr(f2_sel(x.odd, f2_norm(f2_add(c1.b2, c0.b1)), f2_norm(f2_add(c1.b1, c0.b0))));   // even: s6, odd: s8
-    F2 sb_in = f2_norm(f2_add(c0.b2, c1.b0));
-    F2 sb = f2_sqr(sb_in);                                   // s7 (the odd lane's copy is unused: 5 / 4 useful squarings)
-    F6 po = x.swap(own);
-    F2 psa = x.swap(sa), psb = x.swap(sb);
-    F2 t1 = f2_sel(x.odd, po.b0, own.b0), t5 = f2_sel(x.odd, po.b1, own.b1), t2 = f2_sel(x.odd, po.b2, own.b2);
-    F2 t3 = f2_sel(x.odd, own.b0, po.b0), t0 = f2_sel(x.odd, own.b1, po.b1), t4 = f2_sel(x.odd, own.b2, po.b2);
-    F2 s6 = f2_sel(x.odd, psa, sa), s8 = f2_sel(x.odd, sa, psa), s7 = f2_sel(x.odd, psb, sb);
-    // even lane outputs (C0):  3(xi t0 + t1) - 2 c0.b0,  3(xi t2 + t3) - 2 c0.b1,  3(xi t4 + t5) - 2 c0.b2
-    // odd lane outputs  (C1):  3 xi (s8-t4-t5) + 2 c1.b0,  3 (s6-t0-t1) + 2 c1.b1,  3 (s7-t2-t3) + 2 c1.b2
-    F2 e0 = f2_norm(f2_add(f2_mul_xi_n(t0), t1)), e1 = f2_norm(f2_add(f2_mul_xi_n(t2), t3)), e2 = f2_norm(f2_add(f2_mul_xi_n(t4), t5));
-    F2 o0 = f2_mul_xi_n(f2_norm(f2_sub(f2_sub(s8, t4), t5)));
-    F2 o1 = f2_norm(f2_sub(f2_sub(s6, t0), t1)), o2 = f2_norm(f2_sub(f2_sub(s7, t2), t3));
-    F2 tt0 = f2_sel(x.odd, o0, e0), tt1 = f2_sel(x.odd, o1, e1), tt2 = f2_sel(x.odd, o2, e2);
+    F2 q0 = f2_sqr(h.b0), q1 = f2_sqr(h.b1), q2 = f2_sqr(h.b2);        // even: t1,t5,t2   odd: t3,t0,t4
+    F2 sa = f2_sqr_n(f2_add(f2_sel(x.odd, h.b2, h.b0), p.b1));           // even: s6   odd: s8
+    F2 sb = f2_sqr_n(f2_add(h.b2, p.b0));                                 // even: s7   (odd: unused)
+    F2 psa = x.swap(sa), pq0 = x.swap(q0), pq2 = x.swap(q2);
+    F2 A = f2_mul_xi_n(q2);                                               // even: xi t2   odd: xi t4
+    F2 B = f2_mul_xi_n(f2_sel(x.odd, q1, f2_norm(f2_sub(f2_sub(psa, pq2), q1))));   // even: xi (s8-t4-t5)   odd: xi t0
+    F2 pA = x.swap(A), pB = x.swap(B), psb = x.swap(sb);
+    F2 tt0 = f2_sel(x.odd, pB, f2_norm(f2_add(pB, q0)));
+    F2 tt1 = f2_sel(x.odd, f2_norm(f2_sub(f2_sub(psa, q1), pq0)), f2_norm(f2_add(A, pq0)));
+    F2 tt2 = f2_sel(x.odd, f2_norm(f2_sub(f2_sub(psb, pq2), q0)), f2_norm(f2_add(pA, q1)));
     // out = 3 tt -+ 2 own coefficient  (minus on the even lane, plus on the odd lane)
     F6 sgn = f6_sel(x.odd, h, f6_neg(h));
     F6 r{f2_norm(f2_add(f2_dbl(f2_norm(f2_add(tt0, sgn.b0))), tt0)),

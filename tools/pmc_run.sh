@@ -23,5 +23,13 @@ with open(f"{R}/gpurun_out/{TAG}_summary.txt","w") as out:
         if not k.startswith("k_"): continue
         out.write(k+"\n")
         for c in sorted(agg[k]): out.write("   %-28s per-dispatch mean %.6g  (dispatches %d)\n"%(c, agg[k][c]/cnt[k][c], cnt[k][c]))
+import json
+traffic={}
+for k in agg:
+    kk=k.strip('"')
+    if "FETCH_SIZE" in agg[k] and "WRITE_SIZE" in agg[k]:
+        n=cnt[k]["FETCH_SIZE"]
+        traffic[kk]={"fetch_kb": agg[k]["FETCH_SIZE"]/n, "write_kb": agg[k]["WRITE_SIZE"]/cnt[k]["WRITE_SIZE"], "batch": $B if n==1 else min($B,262144), "launches_per_batch": 1}
+json.dump(traffic, open(f"{R}/gpurun_out/{TAG}_traffic.json","w"), indent=1)
 print(open(f"{R}/gpurun_out/{TAG}_summary.txt").read())
 PY

@@ -336,11 +336,11 @@ GPBC_INLINE Fe fe_halve(const Fe &a) {
 }
 
 // Value reduction without a multiplication: subtract k*p with k = round(top limb / p_8).  Input: weakly normalised,
-// |value| < 128p.  Output: |value| < 0.51p, limbs 0..7 within +-(2^29 + 2^8).  Used where a small-constant multiple
+// |value| < 256p.  Output: |value| < 0.51p, limbs 0..7 within +-(2^29 + 2^9).  Used where a small-constant multiple
 // (the non-residue 9+i) would otherwise let the worst-case magnitude compound through the tower.
 GPBC_INLINE Fe fe_reduce(const Fe &a) {
 #ifdef GPBC_BOUNDS
-    if (a.vb >= 128.0) bounds_fail("fe_reduce input value", a.vb, 128.0);
+    if (a.vb >= 256.0) bounds_fail("fe_reduce input value", a.vb, 256.0);
     for (int i = 0; i < NL - 1; i++) if (a.lb[i] > 536870912.0 + 1024) bounds_fail("fe_reduce input limb (normalise first)", a.lb[i], 536870912.0 + 1024);
 #endif
     constexpr int32_t P8 = f29_p(NL - 1);
@@ -355,9 +355,9 @@ GPBC_INLINE Fe fe_reduce(const Fe &a) {
         hi_prev = hi;
     }
 #ifdef GPBC_BOUNDS
-    for (int i = 0; i < NL - 1; i++) r.lb[i] = a.lb[i] + 129;       // lo in [0,2^29) never adds magnitude beyond the input's; hi within +-128
-    for (int i = 0; i < NL - 1; i++) if (r.lb[i] < 536870912.0 + 129) r.lb[i] = 536870912.0 + 129;
-    r.lb[NL - 1] = (double)P8 / 2 + 140;
+    for (int i = 0; i < NL - 1; i++) r.lb[i] = a.lb[i] + 257;       // lo in [0,2^29) never adds magnitude beyond the input's; hi within +-256
+    for (int i = 0; i < NL - 1; i++) if (r.lb[i] < 536870912.0 + 257) r.lb[i] = 536870912.0 + 257;
+    r.lb[NL - 1] = (double)P8 / 2 + 270;
     r.vb = 0.51;
     bound_stats().reduces++;
     check_limbs(r, "fe_reduce limb");

@@ -30,8 +30,7 @@ template <class X, class Src> GPBC_INLINE F6 miller_accumulate_pair(const X &x, 
     return h;
 }
 
-// n squarings; every one value-reduced (the lane-merged worst-case bounds leave no room to skip one, and a lane only
-// carries half of the reductions of the single-lane form anyway)
+// n squarings in place, each value-reduced once on its outputs (its xi products are only normalised)
 template <class X> GPBC_INLINE F6 f12p_cyclo_sqr_n(const X &x, F6 r, int n) {
     for (int i = 0; i < n; i++) r = f12p_cyclo_sqr<true>(x, r);
     return r;

@@ -81,6 +81,8 @@ GPBC_INLINE F2 f2_mul_xi_n(const F2 &x) {
     F2 t = f2_norm(f2_mul_xi(x));
     return F2{fe_reduce(t.a0), fe_reduce(t.a1)};
 }
+GPBC_INLINE F2 f2_mul_xi_nn(const F2 &x) { return f2_norm(f2_mul_xi(x)); }      // N-class out, value NOT reduced (|xi| ~ 10 x)
+template <bool RX> GPBC_INLINE F2 f2_mul_xi_t(const F2 &x) { return RX ? f2_mul_xi_n(x) : f2_mul_xi_nn(x); }
 GPBC_INLINE F2 f2_mul8_norm(const F2 &x) { return F2{fe_mul8_norm(x.a0), fe_mul8_norm(x.a1)}; }
 GPBC_INLINE F2 f2_inv(const F2 &x) {
     Fe n = fe_inv(fe_norm(fe_add(fe_sqr(x.a0), fe_sqr(x.a1))));
@@ -107,18 +109,21 @@ GPBC_INLINE F6 f6_neg(const F6 &x) { return F6{f2_neg(x.b0), f2_neg(x.b1), f2_ne
 GPBC_INLINE F6 f6_norm(const F6 &x) { return F6{f2_norm(x.b0), f2_norm(x.b1), f2_norm(x.b2)}; }
 GPBC_INLINE F6 f6_reduce(const F6 &x) { return F6{f2_reduce(x.b0), f2_reduce(x.b1), f2_reduce(x.b2)}; }
 // x * v: (xi b2, b0, b1); N-class in and out
-GPBC_INLINE F6 f6_mul_v(const F6 &x) { return F6{f2_mul_xi_n(x.b2), x.b0, x.b1}; }
+template <bool RX> GPBC_INLINE F6 f6_mul_v_t(const F6 &x) { return F6{f2_mul_xi_t<RX>(x.b2), x.b0, x.b1}; }
+GPBC_INLINE F6 f6_mul_v(const F6 &x) { return f6_mul_v_t<true>(x); }
 
-GPBC_INLINE F6 f6_mul(const F6 &x, const F6 &y) {
+// RX = false leaves the two xi products un-reduced in value (the caller reduces its own outputs instead)
+template <bool RX> GPBC_INLINE F6 f6_mul_t(const F6 &x, const F6 &y) {
     F2 t0 = f2_mul(x.b0, y.b0), t1 = f2_mul(x.b1, y.b1), t2 = f2_mul(x.b2, y.b2);
     F2 m12 = f2_mul_nn(f2_add(x.b1, x.b2), f2_add(y.b1, y.b2));
     F2 m01 = f2_mul_nn(f2_add(x.b0, x.b1), f2_add(y.b0, y.b1));
     F2 m02 = f2_mul_nn(f2_add(x.b0, x.b2), f2_add(y.b0, y.b2));
-    F2 c0 = f2_add(f2_mul_xi_n(f2_norm(f2_sub(f2_sub(m12, t1), t2))), t0);
-    F2 c1 = f2_add(f2_norm(f2_sub(f2_sub(m01, t0), t1)), f2_mul_xi_n(t2));
+    F2 c0 = f2_add(f2_mul_xi_t<RX>(f2_norm(f2_sub(f2_sub(m12, t1), t2))), t0);
+    F2 c1 = f2_add(f2_norm(f2_sub(f2_sub(m01, t0), t1)), f2_mul_xi_t<RX>(t2));
     F2 c2 = f2_add(f2_sub(f2_sub(m02, t0), t2), t1);
     return F6{f2_norm(c0), f2_norm(c1), f2_norm(c2)};
 }
+GPBC_INLINE F6 f6_mul(const F6 &x, const F6 &y) { return f6_mul_t<true>(x, y); }
 GPBC_INLINE F6 f6_sqr(const F6 &x) {   // CH-SQR2
     F2 s0 = f2_sqr(x.b0);
     F2 m01 = f2_mul(x.b0, x.b1);
@@ -132,13 +137,14 @@ GPBC_INLINE F6 f6_sqr(const F6 &x) {   // CH-SQR2
 }
 GPBC_INLINE F6 f6_mul_f2(const F6 &x, const F2 &k) { return F6{f2_mul(x.b0, k), f2_mul(x.b1, k), f2_mul(x.b2, k)}; }
 // x * (c0 + c1 v); s01 = norm(c0 + c1) supplied by the caller (shared between the two uses in the sparse F12 product)
-GPBC_INLINE F6 f6_mul_01(const F6 &x, const F2 &c0, const F2 &c1, const F2 &s01) {
+template <bool RX> GPBC_INLINE F6 f6_mul_01_t(const F6 &x, const F2 &c0, const F2 &c1, const F2 &s01) {
     F2 a = f2_mul(x.b0, c0), b = f2_mul(x.b1, c1);
-    F2 t0 = f2_add(f2_mul_xi_n(f2_norm(f2_sub(f2_mul(f2_norm(f2_add(x.b1, x.b2)), c1), b))), a);
+    F2 t0 = f2_add(f2_mul_xi_t<RX>(f2_norm(f2_sub(f2_mul(f2_norm(f2_add(x.b1, x.b2)), c1), b))), a);
     F2 t1 = f2_sub(f2_sub(f2_mul(f2_norm(f2_add(x.b0, x.b1)), s01), a), b);
     F2 t2 = f2_add(f2_sub(f2_mul(f2_norm(f2_add(x.b0, x.b2)), c0), a), b);
     return F6{f2_norm(t0), f2_norm(t1), f2_norm(t2)};
 }
+GPBC_INLINE F6 f6_mul_01(const F6 &x, const F2 &c0, const F2 &c1, const F2 &s01) { return f6_mul_01_t<true>(x, c0, c1, s01); }
 GPBC_INLINE F6 f6_inv(const F6 &x) {
     F2 t0 = f2_norm(f2_sub(f2_sqr(x.b0), f2_mul_xi_n(f2_mul(x.b1, x.b2))));
     F2 t1 = f2_norm(f2_sub(f2_mul_xi_n(f2_sqr(x.b2)), f2_mul(x.b0, x.b1)));

@@ -63,12 +63,12 @@ template <class X> GPBC_INLINE F6 f12p_sqr(const X &x, const F6 &h) {
     F6 p = x.swap(h);
     // even lane (h = c0, p = c1): m = h * p.   odd lane (h = c1, p = c0): st = (h + p) * (p + v h).
     F6 s = f6_norm(f6_add(h, p));
-    F6 t = f6_norm(f6_add(p, f6_mul_v(h)));
-    F6 r = f6_mul(f6_sel(x.odd, s, h), f6_sel(x.odd, t, p));            // even: m, odd: st
+    F6 t = f6_norm(f6_add(p, f6_mul_v_t<false>(h)));
+    F6 r = f6_mul_t<false>(f6_sel(x.odd, s, h), f6_sel(x.odd, t, p));   // even: m, odd: st
     F6 pr = x.swap(r);                                                   // even: st, odd: m
-    F6 even_out = f6_norm(f6_sub(f6_sub(pr, r), f6_mul_v(r)));
+    F6 even_out = f6_norm(f6_sub(f6_sub(pr, r), f6_mul_v_t<false>(r)));
     F6 odd_out = f6_norm(f6_dbl(pr));
-    return f6_sel(x.odd, odd_out, even_out);
+    return f6_reduce(f6_sel(x.odd, odd_out, even_out));                  // the one value reduction of this step
 }
 
 // f * (l0 + l1 w), l0 = (c0,0,0), l1 = (c3,c4,0):  C0' = a l0 + v (b l1),  C1' = a l1 + b l0.
@@ -76,16 +76,16 @@ template <class X> GPBC_INLINE F6 f12p_sqr(const X &x, const F6 &h) {
 template <class X> GPBC_INLINE F6 f12p_mul_034(const X &x, const F6 &h, const F2 &c0, const F2 &c3, const F2 &c4) {
     F2 s34 = f2_norm(f2_add(c3, c4));
     F6 r0 = f6_mul_f2(h, c0);
-    F6 r1 = f6_mul_01(h, c3, c4, s34);
+    F6 r1 = f6_mul_01_t<false>(h, c3, c4, s34);
     F6 p1 = x.swap(r1);
-    F6 add = f6_sel(x.odd, p1, f6_mul_v(p1));
-    return f6_norm(f6_add(r0, add));
+    F6 add = f6_sel(x.odd, p1, f6_mul_v_t<false>(p1));
+    return f6_reduce(f6_norm(f6_add(r0, add)));                          // the one value reduction of this step
 }
 
 // full product (Karatsuba over F6).  The third product (a0+a1)(b0+b1) is itself split: the even lane computes its three
 // diagonal F2 products, the odd lane its three cross products.
 template <class X> GPBC_INLINE F6 f12p_mul(const X &x, const F6 &hx, const F6 &hy) {
-    F6 t = f6_mul(hx, hy);                                   // even: t0 = a0 b0, odd: t1 = a1 b1
+    F6 t = f6_mul_t<false>(hx, hy);                          // even: t0 = a0 b0, odd: t1 = a1 b1
     F6 sx = f6_norm(f6_add(hx, x.swap(hx)));
     F6 sy = f6_norm(f6_add(hy, x.swap(hy)));
     // three F2 products per lane of sx * sy
@@ -97,9 +97,9 @@ template <class X> GPBC_INLINE F6 f12p_mul(const X &x, const F6 &hx, const F6 &h
     F6 dg = f6_sel(x.odd, other, mine), cr = f6_sel(x.odd, mine, other);
     F6 pt = x.swap(t);                                        // even: t1, odd: t0
     // one shared xi-multiplication: the odd lane needs xi (m12 - u1 - u2) for m, the even lane xi t1.b2 for v t1
-    F2 xi1 = f2_mul_xi_n(f2_sel(x.odd, f2_norm(f2_sub(f2_sub(cr.b0, dg.b1), dg.b2)), pt.b2));
+    F2 xi1 = f2_mul_xi_nn(f2_sel(x.odd, f2_norm(f2_sub(f2_sub(cr.b0, dg.b1), dg.b2)), pt.b2));
     F2 m0 = f2_add(xi1, dg.b0);
-    F2 m1 = f2_add(f2_norm(f2_sub(f2_sub(cr.b1, dg.b0), dg.b1)), f2_mul_xi_n(dg.b2));
+    F2 m1 = f2_add(f2_norm(f2_sub(f2_sub(cr.b1, dg.b0), dg.b1)), f2_mul_xi_nn(dg.b2));
     F2 m2 = f2_add(f2_sub(f2_sub(cr.b2, dg.b0), dg.b2), dg.b1);
     F6 m{f2_norm(m0), f2_norm(m1), f2_norm(m2)};              // (a0+a1)(b0+b1): meaningful on the odd lane
     F6 even_out = f6_add(t, F6{xi1, pt.b0, pt.b1});           // t0 + v t1
@@ -119,8 +119,9 @@ template <bool REDUCE, class X> GPBC_INLINE F6 f12p_cyclo_sqr(const X &x, const 
     F2 sa = f2_sqr_n(f2_add(f2_sel(x.odd, h.b2, h.b0), p.b1));           // even: s6   odd: s8
     F2 sb = f2_sqr_n(f2_add(h.b2, p.b0));                                 // even: s7   (odd: unused)
     F2 psa = x.swap(sa), pq0 = x.swap(q0), pq2 = x.swap(q2);
-    F2 A = f2_mul_xi_n(q2);                                               // even: xi t2   odd: xi t4
-    F2 B = f2_mul_xi_n(f2_sel(x.odd, q1, f2_norm(f2_sub(f2_sub(psa, pq2), q1))));   // even: xi (s8-t4-t5)   odd: xi t0
+    // (the xi products are only normalised here: the value reduction happens once, on the outputs)
+    F2 A = f2_norm(f2_mul_xi(q2));                                        // even: xi t2   odd: xi t4
+    F2 B = f2_norm(f2_mul_xi(f2_sel(x.odd, q1, f2_norm(f2_sub(f2_sub(psa, pq2), q1)))));   // even: xi (s8-t4-t5)   odd: xi t0
     F2 pA = x.swap(A), pB = x.swap(B), psb = x.swap(sb);
     F2 tt0 = f2_sel(x.odd, pB, f2_norm(f2_add(pB, q0)));
     F2 tt1 = f2_sel(x.odd, f2_norm(f2_sub(f2_sub(psa, q1), pq0)), f2_norm(f2_add(A, pq0)));

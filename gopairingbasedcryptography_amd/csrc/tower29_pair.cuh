@@ -66,9 +66,9 @@ template <class X> GPBC_INLINE F6 f12p_sqr(const X &x, const F6 &h) {
     F6 t = f6_norm(f6_add(p, f6_mul_v_t<false>(h)));
     F6 r = f6_mul_t<false>(f6_sel(x.odd, s, h), f6_sel(x.odd, t, p));   // even: m, odd: st
     F6 pr = x.swap(r);                                                   // even: st, odd: m
-    F6 even_out = f6_norm(f6_sub(f6_sub(pr, r), f6_mul_v_t<false>(r)));
-    F6 odd_out = f6_norm(f6_dbl(pr));
-    return f6_reduce(f6_sel(x.odd, odd_out, even_out));                  // the one value reduction of this step
+    F6 even_out = f6_sub(f6_sub(pr, r), f6_mul_v_t<false>(r));
+    F6 odd_out = f6_dbl(pr);
+    return f6_norm(f6_sel(x.odd, odd_out, even_out));                    // value-reduced by the sparse product that follows
 }
 
 // f * (l0 + l1 w), l0 = (c0,0,0), l1 = (c3,c4,0):  C0' = a l0 + v (b l1),  C1' = a l1 + b l0.

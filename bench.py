@@ -80,8 +80,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = "RANK" in os.environ                      # launched by torch.distributed.run (any world size)
+    if use_dist:
         import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -89,7 +91,7 @@ def main():
     from gopairingbasedcryptography_amd import _build, bn254
     if rank == 0:
         _build.build_library()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     bn254.init(local_rank)
 
@@ -106,7 +108,7 @@ def main():
     gt = torch.empty((B, 384), dtype=torch.uint8, device=dev)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -134,7 +136,7 @@ def main():
         step(ev[s])
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -189,7 +191,7 @@ def main():
             fn(base, ks, out=out)
             barrier()
             d = time.perf_counter() - t1
-            if world > 1:
+            if use_dist:
                 tm = torch.tensor([d], dtype=torch.float64, device=dev)
                 dist.all_reduce(tm, op=dist.ReduceOp.MAX)
                 d = float(tm.item())
@@ -203,7 +205,7 @@ def main():
         result["cpu_baseline"] = cpu_baseline(P, Q, gt, sample, threads)
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -249,3 +249,20 @@ def test_large_batch_chunks_and_properties(eng, oracle):
     QQ = np.repeat(dQ[:m].cpu().numpy(), 2, axis=0)
     ok = eng.pairing_check_batch(PP, QQ, np.arange(0, 2 * m + 1, 2))
     assert ok.all()
+
+
+def test_multi_pair_cpabe_shape(eng, oracle):
+    """BASELINE config 4 shape at test size: 513-pair products (256-attribute BSW07 decrypt: 2*256+1 pairs),
+    16 ciphertexts, one final exponentiation per segment, against the oracle."""
+    import torch
+    segs, m = 16, 513
+    n = segs * m
+    g1, g2 = eng.generators()
+    rng = np.random.default_rng(513)
+    k = np.frombuffer(rng.bytes(32 * n), dtype=np.uint8).copy().reshape(n, 32)
+    k[:, 31] &= 0x1F
+    dk = torch.from_numpy(k).cuda()
+    P = eng.g1_scalar_mul(torch.from_numpy(g1).cuda(), dk).cpu().numpy()
+    Q = eng.g2_scalar_mul(torch.from_numpy(g2).cuda(), dk.flip(0).contiguous()).cpu().numpy()
+    off = np.arange(0, n + 1, m)
+    assert (eng.multi_pair(P, Q, off) == oracle.multi_pair(P, Q, off, threads=16)).all()

@@ -166,13 +166,12 @@ GPBC_INLINE F2 glv_phi_x(const F2 &x) { constexpr int32_t B[NL] = GLV_BETA_G2; r
 GPBC_INLINE Fe g_neg(const Fe &a) { return fe_neg(a); }
 GPBC_INLINE F2 g_neg(const F2 &a) { return f2_neg(a); }
 
-// [k]base for any 256-bit k: interleaved double-and-add over the two ~128-bit halves of the GLV split
-template <class F> GPBC_INLINE void scalar_mul29(AffP<F> &out, const AffP<F> &base, const uint32_t k[8]) {
+// [k]base for any 256-bit k: interleaved double-and-add over the two ~128-bit halves of the GLV split (Jacobian result)
+template <class F> GPBC_INLINE void scalar_mul29_jac(JacP<F> &acc, const AffP<F> &base, const uint32_t k[8]) {
     GlvSplit s;
     glv_split(s, k);
     AffP<F> p1{base.x, s.neg1 ? g_neg(base.y) : base.y, base.inf};
     AffP<F> p2{glv_phi_x(base.x), s.neg2 ? g_neg(base.y) : base.y, base.inf};
-    JacP<F> acc;
     jac_set_inf(acc);
     int top = 159;
     while (top >= 0 && !(((s.k1[top >> 5] | s.k2[top >> 5]) >> (top & 31)) & 1)) top--;
@@ -181,7 +180,33 @@ template <class F> GPBC_INLINE void scalar_mul29(AffP<F> &out, const AffP<F> &ba
         if ((s.k1[i >> 5] >> (i & 31)) & 1) jac_add_mixed(acc, acc, p1);
         if ((s.k2[i >> 5] >> (i & 31)) & 1) jac_add_mixed(acc, acc, p2);
     }
+}
+template <class F> GPBC_INLINE void scalar_mul29(AffP<F> &out, const AffP<F> &base, const uint32_t k[8]) {
+    JacP<F> acc;
+    scalar_mul29_jac(acc, base, k);
     jac_to_affine(out, acc);
+}
+
+// K Jacobian points -> affine with ONE field inversion (Montgomery's trick): the inversion (~380 Fp products by Fermat)
+// is a sixth of a G1 scalar multiplication, so a lane that owns K points amortises it K-fold.
+template <class F, int K> GPBC_INLINE void jac_to_affine_batch(AffP<F> (&out)[K], const JacP<F> (&p)[K]) {
+    F one, pre[K];
+    g_set_one(one);
+    F run = one;
+    for (int j = 0; j < K; j++) {
+        pre[j] = run;                                    // product of the z's before j
+        run = g_mul(run, p[j].inf ? one : p[j].z);
+    }
+    F inv = g_inv(run);
+    for (int j = K - 1; j >= 0; j--) {
+        F zi = g_mul(inv, pre[j]);
+        inv = g_mul(inv, p[j].inf ? one : p[j].z);
+        if (p[j].inf) { g_set_zero(out[j].x); g_set_zero(out[j].y); out[j].inf = true; continue; }
+        F zi2 = g_sqr(zi);
+        out[j].x = g_mul(p[j].x, zi2);
+        out[j].y = g_mul(p[j].y, g_mul(zi2, zi));
+        out[j].inf = false;
+    }
 }
 
 }  // namespace gpbc

@@ -460,15 +460,25 @@ GPBC_INLINE bool bytes_all_zero(const uint8_t *p, int n_words) {
     return o == 0;
 }
 
-// x^(p-2) (0 -> 0), plain square-and-multiply over the fixed exponent
+// x^(p-2) (0 -> 0): fixed 4-bit windows over the constant exponent, left to right (254 squarings + <=64 products + 14
+// for the table, against 127 products for the plain binary method)
 GPBC_NOINLINE Fe fe_inv(const Fe &x) {
-    constexpr int32_t E[NL] = F29_P;      // p - 2: subtract 2 from limb 0 (p's limb 0 is >= 2)
-    Fe r = fe_one(), b = x;
-    for (int i = 0; i < 254; i++) {
+    constexpr int32_t E[NL] = F29_P;              // p - 2: subtract 2 from limb 0 (p's limb 0 is >= 2)
+    Fe tab[16];
+    tab[0] = fe_one();
+    tab[1] = x;
+    for (int i = 2; i < 16; i++) tab[i] = fe_mul(tab[i - 1], x);
+    auto ebit = [&](int i) -> int {
+        if (i < 0 || i >= 254) return 0;
         int limb = i / LB, bit = i % LB;
         int32_t e = E[limb] - (limb == 0 ? 2 : 0);
-        if ((e >> bit) & 1) r = fe_mul(r, b);
-        b = fe_sqr(b);
+        return (e >> bit) & 1;
+    };
+    Fe r = fe_one();
+    for (int w = 63; w >= 0; w--) {               // 64 windows cover bits 255..0 (the top two bits are zero)
+        if (w != 63) { r = fe_sqr(r); r = fe_sqr(r); r = fe_sqr(r); r = fe_sqr(r); }
+        int d = ebit(4 * w) | (ebit(4 * w + 1) << 1) | (ebit(4 * w + 2) << 2) | (ebit(4 * w + 3) << 3);
+        if (d) r = fe_mul(r, tab[d]);
     }
     return r;
 }

@@ -124,23 +124,52 @@ __device__ __forceinline__ AffP<F2> g2_load_aff(const uint8_t *p) { return AffP<
 __device__ __forceinline__ void g1_store_aff(uint8_t *p, const AffP<Fe> &r) { fe_store(p, r.x); fe_store(p + 32, r.y); }
 __device__ __forceinline__ void g2_store_aff(uint8_t *p, const AffP<F2> &r) { f2_store(p, r.x); f2_store(p + 64, r.y); }
 
+// Scalar multiplication: a lane owns SMUL_K points (t, t+T, t+2T, ...; T = ceil(n / SMUL_K)) whose Jacobian results share
+// one field inversion.  Measured on MI355X (2^20 points): K = 1 -> 36.9 M G1 / 15.0 M G2 per second, K = 2 -> 36.9 / 13.7,
+// K = 4 -> 35.9 / 13.3: holding K results costs more in registers and scratch than the shared inversion saves, so K = 1.
+#ifndef GPBC_SMUL_K
+#define GPBC_SMUL_K 1
+#endif
+constexpr int SMUL_K = GPBC_SMUL_K;
 GPBC_KERNEL k_g1_scalar_mul(const uint8_t *__restrict__ bases, int shared_base, const uint8_t *__restrict__ scalars, uint8_t *__restrict__ out, size_t n) {
-    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    AffP<Fe> b = g1_load_aff(bases + (shared_base ? 0 : i * GPBC_G1_BYTES)), r;
-    uint32_t k[8];
-    load_scalar(k, scalars + i * GPBC_SCALAR_BYTES);
-    scalar_mul29<Fe>(r, b, k);
-    g1_store_aff(out + i * GPBC_G1_BYTES, r);
+    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    size_t T = (n + SMUL_K - 1) / SMUL_K;
+    if (t >= T) return;
+    JacP<Fe> res[SMUL_K];
+    for (int j = 0; j < SMUL_K; j++) {
+        size_t i = t + (size_t)j * T;
+        if (i >= n) { jac_set_inf(res[j]); continue; }
+        AffP<Fe> b = g1_load_aff(bases + (shared_base ? 0 : i * GPBC_G1_BYTES));
+        uint32_t k[8];
+        load_scalar(k, scalars + i * GPBC_SCALAR_BYTES);
+        scalar_mul29_jac<Fe>(res[j], b, k);
+    }
+    AffP<Fe> aff[SMUL_K];
+    jac_to_affine_batch<Fe, SMUL_K>(aff, res);
+    for (int j = 0; j < SMUL_K; j++) {
+        size_t i = t + (size_t)j * T;
+        if (i < n) g1_store_aff(out + i * GPBC_G1_BYTES, aff[j]);
+    }
 }
 GPBC_KERNEL k_g2_scalar_mul(const uint8_t *__restrict__ bases, int shared_base, const uint8_t *__restrict__ scalars, uint8_t *__restrict__ out, size_t n) {
-    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    AffP<F2> b = g2_load_aff(bases + (shared_base ? 0 : i * GPBC_G2_BYTES)), r;
-    uint32_t k[8];
-    load_scalar(k, scalars + i * GPBC_SCALAR_BYTES);
-    scalar_mul29<F2>(r, b, k);
-    g2_store_aff(out + i * GPBC_G2_BYTES, r);
+    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    size_t T = (n + SMUL_K - 1) / SMUL_K;
+    if (t >= T) return;
+    JacP<F2> res[SMUL_K];
+    for (int j = 0; j < SMUL_K; j++) {
+        size_t i = t + (size_t)j * T;
+        if (i >= n) { jac_set_inf(res[j]); continue; }
+        AffP<F2> b = g2_load_aff(bases + (shared_base ? 0 : i * GPBC_G2_BYTES));
+        uint32_t k[8];
+        load_scalar(k, scalars + i * GPBC_SCALAR_BYTES);
+        scalar_mul29_jac<F2>(res[j], b, k);
+    }
+    AffP<F2> aff[SMUL_K];
+    jac_to_affine_batch<F2, SMUL_K>(aff, res);
+    for (int j = 0; j < SMUL_K; j++) {
+        size_t i = t + (size_t)j * T;
+        if (i < n) g2_store_aff(out + i * GPBC_G2_BYTES, aff[j]);
+    }
 }
 
 // one level of the point-sum tree: thread t adds in[t], in[t+n_out], in[t+2 n_out], ... -> out[t] (affine)
@@ -369,8 +398,9 @@ static int scalar_mul_dev(bool g2, const void *d_bases, size_t nbase, const void
     if (nbase != 1 && nbase != n) return fail(GPBC_ERR_INVALID_ARG, "nbase must be 1 or n");
     TRY(bind_device());
     int shared = (nbase == 1 && n != 1) ? 1 : 0;
-    if (g2) k_g2_scalar_mul<<<grid_for(n), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_bases, shared, (const uint8_t *)d_scalars, (uint8_t *)d_out, n);
-    else k_g1_scalar_mul<<<grid_for(n), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_bases, shared, (const uint8_t *)d_scalars, (uint8_t *)d_out, n);
+    size_t lanes = (n + SMUL_K - 1) / SMUL_K;
+    if (g2) k_g2_scalar_mul<<<grid_for(lanes), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_bases, shared, (const uint8_t *)d_scalars, (uint8_t *)d_out, n);
+    else k_g1_scalar_mul<<<grid_for(lanes), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_bases, shared, (const uint8_t *)d_scalars, (uint8_t *)d_out, n);
     return check_launch(g2 ? "k_g2_scalar_mul" : "k_g1_scalar_mul");
 }
 int gpbc_g1_scalar_mul_batch_dev(const void *b, size_t nb, const void *s, size_t n, void *o, void *st) { return scalar_mul_dev(false, b, nb, s, n, o, st); }

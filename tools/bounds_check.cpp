@@ -44,6 +44,23 @@ static std::mutex g_stats_mu;
 static BoundStats g_stats_total;
 static void stats_flush() { std::lock_guard<std::mutex> lk(g_stats_mu); bound_stats_merge(g_stats_total, bound_stats()); }
 
+template <class F, class LoadA, class StoreA> static void smul_batch(const uint8_t *B, const uint8_t *K, size_t n, uint8_t *out, size_t pt, LoadA ld, StoreA st) {
+    constexpr int KK = 4;                                  // same grouping as the kernels: one shared inversion per 4 points
+    size_t T = (n + KK - 1) / KK;
+    for (size_t t = 0; t < T; t++) {
+        JacP<F> res[KK];
+        for (int j = 0; j < KK; j++) {
+            size_t i = t + (size_t)j * T;
+            if (i >= n) { jac_set_inf(res[j]); continue; }
+            uint32_t k[8]; memcpy(k, K + 32 * i, 32);
+            scalar_mul29_jac<F>(res[j], ld(B + pt * i), k);
+        }
+        AffP<F> aff[KK];
+        jac_to_affine_batch<F, KK>(aff, res);
+        for (int j = 0; j < KK; j++) { size_t i = t + (size_t)j * T; if (i < n) st(out + pt * i, aff[j]); }
+    }
+}
+
 extern "C" {
 
 void hc_pair(const uint8_t *P, const uint8_t *Q, size_t n, uint8_t *out) {
@@ -70,20 +87,14 @@ void hc_final_exp(const uint8_t *F, size_t n, uint8_t *out) {
     for (size_t i = 0; i < n; i++) { F12 f; f12_load(f, F + 384 * i); f12_store(out + 384 * i, final_exp29(f)); }
 }
 void hc_g1_mul(const uint8_t *B, const uint8_t *K, size_t n, uint8_t *out) {
-    for (size_t i = 0; i < n; i++) {
-        AffP<Fe> b{fe_load(B + 64 * i), fe_load(B + 64 * i + 32), bytes_all_zero(B + 64 * i, 16)}, r;
-        uint32_t k[8]; memcpy(k, K + 32 * i, 32);
-        scalar_mul29<Fe>(r, b, k);
-        fe_store(out + 64 * i, r.x); fe_store(out + 64 * i + 32, r.y);
-    }
+    smul_batch<Fe>(B, K, n, out, 64,
+                   [](const uint8_t *p) { return AffP<Fe>{fe_load(p), fe_load(p + 32), bytes_all_zero(p, 16)}; },
+                   [](uint8_t *p, const AffP<Fe> &r) { fe_store(p, r.x); fe_store(p + 32, r.y); });
 }
 void hc_g2_mul(const uint8_t *B, const uint8_t *K, size_t n, uint8_t *out) {
-    for (size_t i = 0; i < n; i++) {
-        AffP<F2> b{f2_load(B + 128 * i), f2_load(B + 128 * i + 64), bytes_all_zero(B + 128 * i, 32)}, r;
-        uint32_t k[8]; memcpy(k, K + 32 * i, 32);
-        scalar_mul29<F2>(r, b, k);
-        f2_store(out + 128 * i, r.x); f2_store(out + 128 * i + 64, r.y);
-    }
+    smul_batch<F2>(B, K, n, out, 128,
+                   [](const uint8_t *p) { return AffP<F2>{f2_load(p), f2_load(p + 64), bytes_all_zero(p, 32)}; },
+                   [](uint8_t *p, const AffP<F2> &r) { f2_store(p, r.x); f2_store(p + 64, r.y); });
 }
 // GLV split of n 256-bit scalars: out rows = [k1 (5 x u32), k2 (5 x u32), neg1, neg2] as 12 u32
 void hc_glv_split(const uint8_t *K, size_t n, uint32_t *out) {

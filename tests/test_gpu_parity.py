@@ -289,3 +289,17 @@ def test_aggregate_verify_single_gpu(eng):
     # HBM-resident inputs take the same path
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     assert sharding.aggregate_verify(eng, d(pk), d(rho), d(sig), H, g1, neg) is True
+
+
+def test_bsw07_batched_decrypt_on_gpu(eng, oracle):
+    """Config 4 semantics on the GPU engine: keys, ciphertexts, folded one-multi-pairing decryption of 6 ciphertexts; the
+    result equals the message and the oracle's reference-shaped (pairing-by-pairing) evaluation bit for bit."""
+    from bsw07_fixture import Instance, example_tree
+    from gopairingbasedcryptography_amd import bsw07
+    inst = Instance(eng, example_tree(), user_attrs=[11, 22, 33], n_ct=6)
+    plan = bsw07.decrypt_plan(inst.tree, inst.user_attrs)
+    folded = bsw07.fold_key(eng, plan, inst.dj, inst.dj_prime)
+    out = bsw07.decrypt_batch(eng, folded, inst.D, inst.cts, Instance.neg_g1)
+    for t, ct in enumerate(inst.cts):
+        assert (out[t] == inst.msgs[t]).all()
+        assert (out[t] == inst.reference_shaped_decrypt(oracle, ct)).all()

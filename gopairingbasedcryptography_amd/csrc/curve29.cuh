@@ -97,10 +97,7 @@ template <class F> GPBC_INLINE void jac_to_affine(AffP<F> &r, const JacP<F> &p) 
 struct GlvSplit { uint32_t k1[5], k2[5]; bool neg1, neg2; };
 
 template <int NA, int NB, int NO> GPBC_INLINE void mp_mul(uint32_t (&out)[NO], const uint32_t (&a)[NA], const uint32_t (&b)[NB]) {
-    // out = low NO limbs of a * b
-    uint64_t col[NO + 1];
-#pragma unroll
-    for (int i = 0; i <= NO; i++) col[i] = 0;
+    // out = low NO limbs of a * b (column-wise; a column sum of up to 8 32x32 products is kept as two 64-bit halves)
     uint64_t carry = 0;
 #pragma unroll
     for (int k = 0; k < NO; k++) {
@@ -116,7 +113,6 @@ template <int NA, int NB, int NO> GPBC_INLINE void mp_mul(uint32_t (&out)[NO], c
         out[k] = (uint32_t)lo;
         carry = (lo >> 32) + hi;
     }
-    (void)col;
 }
 template <int N> GPBC_INLINE void mp_sub(uint32_t (&r)[N], const uint32_t (&a)[N], const uint32_t (&b)[N]) {
     uint64_t borrow = 0;

@@ -109,7 +109,9 @@ template <class Src> GPBC_INLINE F12 miller_accumulate(Src &&next) {
     return f;
 }
 
-// Both phases in one call (host harness; small device uses): lines staged in a local array
+// Both phases in one call on one lane.  The kernels do not use this form (phase B and the final exponentiation run on
+// lane pairs, pairing29_pair.cuh); it is the single-lane statement of the same mathematics that tools/bounds_check.cpp
+// runs under bound instrumentation and compares with the oracle.
 GPBC_INLINE F12 miller_loop29(const G1A &p, const G2A &q) {
     LineS lines[MILLER_LINES];
     int n = 0;

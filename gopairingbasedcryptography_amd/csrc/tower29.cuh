@@ -31,12 +31,15 @@ GPBC_INLINE bool f2_is_zero(const F2 &x) { return fe_is_zero(x.a0) && fe_is_zero
 // of the Karatsuba layers above), so that the normalisation code lives inside the leaf instead of at every call site.
 template <bool NORM> GPBC_INLINE F2 f2_mul_core(const F2 &xx, const F2 &yy) {
     F2 x = NORM ? f2_norm(xx) : xx, y = NORM ? f2_norm(yy) : yy;
-    return F2{fe_mul_core<true>(x.a0, y.a0, fe_neg(x.a1), y.a1), fe_mul_core<true>(x.a0, y.a1, x.a1, y.a0)};
+    F2 r;
+    fe_mul2_dual(r.a0, r.a1, x.a0, y.a0, fe_neg(x.a1), y.a1, x.a0, y.a1, x.a1, y.a0);
+    return r;
 }
 template <bool NORM> GPBC_INLINE F2 f2_sqr_core(const F2 &xx) {
     F2 x = NORM ? f2_norm(xx) : xx;
-    return F2{fe_mul_core<false>(fe_norm(fe_add(x.a0, x.a1)), fe_norm(fe_sub(x.a0, x.a1)), x.a0, x.a0),
-              fe_mul_core<false>(fe_dbl(x.a0), x.a1, x.a0, x.a0)};
+    F2 r;
+    fe_mul_dual(r.a0, r.a1, fe_norm(fe_add(x.a0, x.a1)), fe_norm(fe_sub(x.a0, x.a1)), fe_dbl(x.a0), x.a1);
+    return r;
 }
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(GPBC_BOUNDS) && !defined(GPBC_INLINE_LEAVES)
 // F2-level leaves: one call per F2 product / squaring, all 36 / 18 limbs as scalar arguments (VGPRs; the last few of

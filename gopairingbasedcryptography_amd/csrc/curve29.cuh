@@ -162,19 +162,47 @@ GPBC_INLINE F2 glv_phi_x(const F2 &x) { constexpr int32_t B[NL] = GLV_BETA_G2; r
 GPBC_INLINE Fe g_neg(const Fe &a) { return fe_neg(a); }
 GPBC_INLINE F2 g_neg(const F2 &a) { return f2_neg(a); }
 
-// [k]base for any 256-bit k: interleaved double-and-add over the two ~128-bit halves of the GLV split (Jacobian result)
+// Affine sum of two affine points with different x (P and phi(P) always differ in x on the prime-order groups)
+template <class F> GPBC_INLINE AffP<F> aff_add_distinct(const AffP<F> &p, const AffP<F> &q) {
+    F lam = g_mul(g_norm(g_sub(q.y, p.y)), g_inv(g_norm(g_sub(q.x, p.x))));
+    F x3 = g_norm(g_sub(g_sub(g_sqr(lam), p.x), q.x));
+    F y3 = g_norm(g_sub(g_mul(lam, g_norm(g_sub(p.x, x3))), p.y));
+    return AffP<F>{x3, y3, p.inf};
+}
+template <class F> GPBC_INLINE F g_sel(bool c, const F &a, const F &b);
+template <> GPBC_INLINE Fe g_sel<Fe>(bool c, const Fe &a, const Fe &b) {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.v[i] = c ? a.v[i] : b.v[i];
+#ifdef GPBC_BOUNDS
+    for (int i = 0; i < NL; i++) r.lb[i] = a.lb[i] > b.lb[i] ? a.lb[i] : b.lb[i];
+    r.vb = a.vb > b.vb ? a.vb : b.vb;
+#endif
+    return r;
+}
+template <> GPBC_INLINE F2 g_sel<F2>(bool c, const F2 &a, const F2 &b) { return F2{g_sel<Fe>(c, a.a0, b.a0), g_sel<Fe>(c, a.a1, b.a1)}; }
+
+// [k]base for any 256-bit k (Jacobian result).  GLV split k = k1 + k2*lambda, then ONE joint double-and-add over the
+// ~128-bit halves with the table {P1, P2, P1+P2} (P1 = +-P, P2 = +-phi(P)): every step is a doubling plus at most one
+// mixed addition.  In a 64-lane wave a per-lane `if (bit) add` costs the addition whenever ANY lane has the bit set, i.e.
+// practically always; two separate conditional additions per step therefore cost two additions per step for the wave,
+// the joint table costs one — that is worth the extra inversion that makes P1+P2 affine.
 template <class F> GPBC_INLINE void scalar_mul29_jac(JacP<F> &acc, const AffP<F> &base, const uint32_t k[8]) {
     GlvSplit s;
     glv_split(s, k);
     AffP<F> p1{base.x, s.neg1 ? g_neg(base.y) : base.y, base.inf};
     AffP<F> p2{glv_phi_x(base.x), s.neg2 ? g_neg(base.y) : base.y, base.inf};
+    AffP<F> p3 = aff_add_distinct(p1, p2);
     jac_set_inf(acc);
     int top = 159;
     while (top >= 0 && !(((s.k1[top >> 5] | s.k2[top >> 5]) >> (top & 31)) & 1)) top--;
     for (int i = top; i >= 0; i--) {
         jac_dbl(acc, acc);
-        if ((s.k1[i >> 5] >> (i & 31)) & 1) jac_add_mixed(acc, acc, p1);
-        if ((s.k2[i >> 5] >> (i & 31)) & 1) jac_add_mixed(acc, acc, p2);
+        const bool b1 = (s.k1[i >> 5] >> (i & 31)) & 1, b2 = (s.k2[i >> 5] >> (i & 31)) & 1;
+        if (b1 || b2) {
+            AffP<F> t{g_sel<F>(b1 && b2, p3.x, g_sel<F>(b1, p1.x, p2.x)), g_sel<F>(b1 && b2, p3.y, g_sel<F>(b1, p1.y, p2.y)), base.inf};
+            jac_add_mixed(acc, acc, t);
+        }
     }
 }
 template <class F> GPBC_INLINE void scalar_mul29(AffP<F> &out, const AffP<F> &base, const uint32_t k[8]) {

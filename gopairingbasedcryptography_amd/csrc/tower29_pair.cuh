@@ -117,12 +117,18 @@ template <bool REDUCE, class X> GPBC_INLINE F6 f12p_cyclo_sqr(const X &x, const 
     F6 p = x.swap(h);
     F2 q0 = f2_sqr(h.b0), q1 = f2_sqr(h.b1), q2 = f2_sqr(h.b2);        // even: t1,t5,t2   odd: t3,t0,t4
     F2 sa = f2_sqr_n(f2_add(f2_sel(x.odd, h.b2, h.b0), p.b1));           // even: s6   odd: s8
-    F2 sb = f2_sqr_n(f2_add(h.b2, p.b0));                                 // even: s7   (odd: unused)
+    // s7 = (C0.b2 + C1.b0)^2 is the ninth squaring: its two Fe products are shared, the even lane forms the real part
+    // (u0+u1)(u0-u1), the odd lane the imaginary part 2 u0 u1, so each lane carries 4.5 squarings.
+    F2 u = f2_norm(f2_add(f2_sel(x.odd, p.b2, h.b2), f2_sel(x.odd, h.b0, p.b0)));        // C0.b2 + C1.b0 on both lanes
+    Fe half = fe_mul(fe_sel(x.odd, fe_dbl(u.a0), fe_norm(fe_add(u.a0, u.a1))), fe_sel(x.odd, u.a1, fe_norm(fe_sub(u.a0, u.a1))));
+    Fe phalf = x.swap(half);
+    F2 sb{fe_sel(x.odd, phalf, half), fe_sel(x.odd, half, phalf)};        // s7 on both lanes
     F2 psa = x.swap(sa), pq0 = x.swap(q0), pq2 = x.swap(q2);
     // (the xi products are only normalised here: the value reduction happens once, on the outputs)
     F2 A = f2_norm(f2_mul_xi(q2));                                        // even: xi t2   odd: xi t4
     F2 B = f2_norm(f2_mul_xi(f2_sel(x.odd, q1, f2_norm(f2_sub(f2_sub(psa, pq2), q1)))));   // even: xi (s8-t4-t5)   odd: xi t0
-    F2 pA = x.swap(A), pB = x.swap(B), psb = x.swap(sb);
+    F2 pA = x.swap(A), pB = x.swap(B);
+    const F2 &psb = sb;
     F2 tt0 = f2_sel(x.odd, pB, f2_norm(f2_add(pB, q0)));
     F2 tt1 = f2_sel(x.odd, f2_norm(f2_sub(f2_sub(psa, q1), pq0)), f2_norm(f2_add(A, pq0)));
     F2 tt2 = f2_sel(x.odd, f2_norm(f2_sub(f2_sub(psb, pq2), q0)), f2_norm(f2_add(pA, q1)));

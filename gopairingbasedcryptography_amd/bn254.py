@@ -136,6 +136,8 @@ def multi_pair(P, Q, seg_off, out=None, workspace=None):
         if not _is_torch(seg_off):
             seg_off = torch.as_tensor(np.ascontiguousarray(seg_off, dtype=np.int64), device=P.device)
         k = seg_off.numel() - 1
+        if k < 1 or int(seg_off[0].item()) != 0 or int(seg_off[-1].item()) != n:
+            raise ValueError("invalid inputs sizes")          # the segment table must cover exactly the n pairs
         out = _tnew(P, k, GT_BYTES) if out is None else out
         wsb = lib.gpbc_multi_pair_workspace_bytes(n, k)
         if workspace is None:

@@ -90,11 +90,15 @@ GPBC_KERNEL k_final_exp(const uint8_t *f_in, uint8_t *gt_out, size_t n) {
 }
 
 // product of the Miller functions of each segment: thread j multiplies f[seg_off[j] .. seg_off[j+1])
-GPBC_KERNEL k_segment_product(const uint8_t *__restrict__ f, const uint64_t *__restrict__ seg_off, uint8_t *__restrict__ out, size_t k) {
+// (the segment table lives in device memory and cannot be validated by the host without a copy: offsets are clamped to
+// the number of pairs so that a malformed table can never read outside the Miller-value buffer)
+GPBC_KERNEL k_segment_product(const uint8_t *__restrict__ f, const uint64_t *__restrict__ seg_off, uint8_t *__restrict__ out, size_t k, size_t n_pairs) {
     size_t j = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (j >= k) return;
     F12 acc = f12_one(), t;
     uint64_t lo = seg_off[j], hi = seg_off[j + 1];
+    if (hi > n_pairs) hi = n_pairs;
+    if (lo > hi) lo = hi;
     for (uint64_t i = lo; i < hi; i++) {
         f12_load(t, f + i * GPBC_GT_BYTES);
         acc = f12_mul(acc, t);
@@ -388,7 +392,7 @@ int gpbc_multi_pair_dev(const void *dP, const void *dQ, const uint64_t *d_seg_of
     if (!d_seg_off || !d_gt_out || (n_pairs && (!dP || !dQ || !d_workspace))) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
     if (workspace_bytes < gpbc_multi_pair_workspace_bytes(n_pairs, k)) return fail(GPBC_ERR_WORKSPACE, "workspace too small");
     TRY(gpbc_miller_loop_dev(dP, dQ, n_pairs, d_workspace, stream));
-    k_segment_product<<<grid_for(k), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_workspace, d_seg_off, (uint8_t *)d_gt_out, k);
+    k_segment_product<<<grid_for(k), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_workspace, d_seg_off, (uint8_t *)d_gt_out, k, n_pairs);
     TRY(check_launch("k_segment_product"));
     return gpbc_final_exp_dev(d_gt_out, k, d_gt_out, stream);
 }

@@ -60,7 +60,9 @@ int gpbc_pair_batch_dev(const void *dP, const void *dQ, size_t n, void *d_gt_out
 /* bn254.Pair with len>1, k times: segment j is pairs [seg_off[j], seg_off[j+1]); one Miller loop per
  * pair, one final exponentiation per segment (products assembled by callers: ibe/bb04_ibe/bb04_ibe.go:213-225,
  * access/tree/access_tree_node.go:106-157, bibe/afp25_bibe/afp25_bibe.go:395-413).
- * seg_off has k+1 non-decreasing entries, seg_off[0] == 0; an empty segment yields GT one. */
+ * seg_off has k+1 non-decreasing entries, seg_off[0] == 0, seg_off[k] == number of pairs; an empty segment yields GT
+ * one.  The host entry validates the table; the _dev entry cannot (the table is in device memory) and clamps every
+ * offset to n_pairs instead, so a malformed table yields wrong products but never an out-of-bounds access. */
 int gpbc_multi_pair(const void *P, const void *Q, const uint64_t *seg_off, size_t k, void *gt_out);
 size_t gpbc_multi_pair_workspace_bytes(size_t n_pairs, size_t k);
 int gpbc_multi_pair_dev(const void *dP, const void *dQ, const uint64_t *d_seg_off, size_t n_pairs, size_t k,

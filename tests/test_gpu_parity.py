@@ -200,6 +200,10 @@ def test_device_pointer_path(eng, synth):
     k = torch.from_numpy(scalars("s", P.shape[0]).copy()).cuda()
     assert (eng.g1_scalar_mul(dP, k).cpu().numpy() == eng.g1_scalar_mul(P, k.cpu().numpy())).all()
     assert (eng.g1_sum(dP).cpu().numpy() == eng.g1_sum(P)).all()
+    with pytest.raises(ValueError, match="invalid inputs sizes"):       # segment table must cover exactly the pairs given
+        eng.multi_pair(dP, dQ, np.array([0, 5, 500]))
+    with pytest.raises(ValueError, match="invalid inputs sizes"):
+        eng.multi_pair(P, Q, np.array([0, 5, 100]))
 
 
 def test_cpp_host_mirror_bls_flow(eng, tmp_path):

@@ -307,3 +307,14 @@ def test_bsw07_batched_decrypt_on_gpu(eng, oracle):
     for t, ct in enumerate(inst.cts):
         assert (out[t] == inst.msgs[t]).all()
         assert (out[t] == inst.reference_shaped_decrypt(oracle, ct)).all()
+
+
+def test_afp25_batched_decrypt_on_gpu(eng, oracle):
+    """Config 5 semantics on the GPU engine: batch of 8 identities, 5 ciphertexts decrypted with one multi_pair call."""
+    from afp25_fixture import Instance
+    from gopairingbasedcryptography_amd import afp25
+    inst = Instance(eng, B=8, n_items=5)
+    out = afp25.decrypt_batch(eng, inst.g1, inst.tau_powers, inst.D, inst.f, inst.sk, inst.items)
+    for t, item in enumerate(inst.items):
+        assert (out[t] == inst.msgs[t]).all()
+        assert (out[t] == inst.reference_shaped_decrypt(oracle, item)).all()

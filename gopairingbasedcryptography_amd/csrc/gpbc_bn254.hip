@@ -505,13 +505,34 @@ static int multi_pair_host(const void *P, const void *Q, const uint64_t *seg_off
     TRY(check_segments(seg_off, k, &n_pairs));
     if ((n_pairs && (!P || !Q)) || (!gt_out && !ok_out)) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
     TRY(bind_device());
-    DevBuf dP, dQ, dS, dG, dW, dOk;
+    DevBuf dP, dQ, dG, dW, dOk, dChunkOff, dSegChunk, dPart;
     TRY(dP.upload(P, n_pairs * GPBC_G1_BYTES)); TRY(dQ.upload(Q, n_pairs * GPBC_G2_BYTES));
-    TRY(dS.upload(seg_off, (k + 1) * sizeof(uint64_t)));
     TRY(dG.alloc(k * GPBC_GT_BYTES));
     size_t wsb = gpbc_multi_pair_workspace_bytes(n_pairs, k);
     TRY(dW.alloc(wsb));
-    TRY(gpbc_multi_pair_dev(dP.p, dQ.p, (const uint64_t *)dS.p, n_pairs, k, dG.p, dW.p, wsb, nullptr));
+    // The segment table is on the host here, so the per-segment product is done in two levels: chunks of SEG_CHUNK
+    // Miller values (one lane per chunk), then the chunk products of each segment (one lane per segment).  A single
+    // bn254.Pair call with hundreds of pairs (ibe/bb04_ibe/bb04_ibe.go:213-225: 257; a 256-attribute BSW07 decrypt: 513)
+    // then costs ~SEG_CHUNK + len/SEG_CHUNK sequential Fp12 products instead of len.
+    constexpr uint64_t SEG_CHUNK = 16;
+    std::vector<uint64_t> chunk_off(1, 0), seg_chunk(1, 0);
+    for (size_t j = 0; j < k; j++) {
+        for (uint64_t a = seg_off[j]; a < seg_off[j + 1]; a += SEG_CHUNK)
+            chunk_off.push_back(a + SEG_CHUNK < seg_off[j + 1] ? a + SEG_CHUNK : seg_off[j + 1]);
+        seg_chunk.push_back(chunk_off.size() - 1);
+    }
+    size_t n_chunks = chunk_off.size() - 1;
+    TRY(dChunkOff.upload(chunk_off.data(), chunk_off.size() * sizeof(uint64_t)));
+    TRY(dSegChunk.upload(seg_chunk.data(), seg_chunk.size() * sizeof(uint64_t)));
+    TRY(dPart.alloc(n_chunks * GPBC_GT_BYTES));
+    TRY(gpbc_miller_loop_dev(dP.p, dQ.p, n_pairs, dW.p, nullptr));
+    if (n_chunks) {
+        k_segment_product<<<grid_for(n_chunks), BLOCK>>>(dW.u8(), (const uint64_t *)dChunkOff.p, dPart.u8(), n_chunks, n_pairs);
+        TRY(check_launch("k_segment_product (chunks)"));
+    }
+    k_segment_product<<<grid_for(k), BLOCK>>>(dPart.u8(), (const uint64_t *)dSegChunk.p, dG.u8(), k, n_chunks);
+    TRY(check_launch("k_segment_product (segments)"));
+    TRY(gpbc_final_exp_dev(dG.p, k, dG.p, nullptr));
     if (ok_out) {
         TRY(dOk.alloc(k));
         k_gt_is_one<<<grid_for(k), BLOCK>>>(dG.u8(), dOk.u8(), k);

@@ -148,10 +148,11 @@ def main():
         "metric": "BN254 pairings/s at batch 2^20 per GPU (+ G1/G2 scalar-mults/s in `secondary`)",
         "value": value, "unit": "pairings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "int32 limbs x9 (254-bit Montgomery integers, int64 MAC accumulators)", "data": "synthetic",
+        "vs_baseline": None, "dtype": "int64", "data": "synthetic",
         "config": {"workload": "configs[1]: batch of %d independent bn254.Pair on random (G1,G2) points per GPU, "
                                "bit-exact vs oracle" % B,
-                   "batch_per_gpu": B, "sharding": "independent index ranges per rank, no data-path collective"},
+                   "batch_per_gpu": B, "sharding": "independent index ranges per rank, no data-path collective",
+                   "arithmetic": "254-bit Montgomery integers as 9 signed 29-bit limbs (int32), 32x32+64-bit MACs into int64 columns"},
     }
     # ---- roofline, VALU integer-MAC bound.  One step launches the Miller stage (k_miller_lines + k_miller_accumulate per
     # 262144-pair chunk) and ONE k_final_exp over the whole batch; the dominant kernel is whichever stage took longer.

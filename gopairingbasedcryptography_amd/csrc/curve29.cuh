@@ -162,13 +162,6 @@ GPBC_INLINE F2 glv_phi_x(const F2 &x) { constexpr int32_t B[NL] = GLV_BETA_G2; r
 GPBC_INLINE Fe g_neg(const Fe &a) { return fe_neg(a); }
 GPBC_INLINE F2 g_neg(const F2 &a) { return f2_neg(a); }
 
-// Affine sum of two affine points with different x (P and phi(P) always differ in x on the prime-order groups)
-template <class F> GPBC_INLINE AffP<F> aff_add_distinct(const AffP<F> &p, const AffP<F> &q) {
-    F lam = g_mul(g_norm(g_sub(q.y, p.y)), g_inv(g_norm(g_sub(q.x, p.x))));
-    F x3 = g_norm(g_sub(g_sub(g_sqr(lam), p.x), q.x));
-    F y3 = g_norm(g_sub(g_mul(lam, g_norm(g_sub(p.x, x3))), p.y));
-    return AffP<F>{x3, y3, p.inf};
-}
 template <class F> GPBC_INLINE F g_sel(bool c, const F &a, const F &b);
 template <> GPBC_INLINE Fe g_sel<Fe>(bool c, const Fe &a, const Fe &b) {
     Fe r;
@@ -186,13 +179,22 @@ template <> GPBC_INLINE F2 g_sel<F2>(bool c, const F2 &a, const F2 &b) { return 
 // ~128-bit halves with the table {P1, P2, P1+P2} (P1 = +-P, P2 = +-phi(P)): every step is a doubling plus at most one
 // mixed addition.  In a 64-lane wave a per-lane `if (bit) add` costs the addition whenever ANY lane has the bit set, i.e.
 // practically always; two separate conditional additions per step therefore cost two additions per step for the wave,
-// the joint table costs one — that is worth the extra inversion that makes P1+P2 affine.
+// the joint table costs one.
+// P1+P2 is kept "affine" without an inversion: with H = x2 - x1 the three table points share the Jacobian Z = H,
+//   P1 = (x1 H^2, y1 H^3, H),  P2 = (x2 H^2, y2 H^3, H),  P1+P2 = (R^2 - H^3 - 2 x1 H^2, R (x1 H^2 - X3) - y1 H^3, H),  R = y2 - y1,
+// i.e. they are affine points of the isomorphic curve y^2 = x^3 + b H^6; the a = 0 doubling and the mixed addition do not
+// involve b, so the whole loop runs there and the result (X, Y, Z') maps back as (X, Y, Z' H).
 template <class F> GPBC_INLINE void scalar_mul29_jac(JacP<F> &acc, const AffP<F> &base, const uint32_t k[8]) {
     GlvSplit s;
     glv_split(s, k);
-    AffP<F> p1{base.x, s.neg1 ? g_neg(base.y) : base.y, base.inf};
-    AffP<F> p2{glv_phi_x(base.x), s.neg2 ? g_neg(base.y) : base.y, base.inf};
-    AffP<F> p3 = aff_add_distinct(p1, p2);
+    F y1 = s.neg1 ? g_neg(base.y) : base.y, y2 = s.neg2 ? g_neg(base.y) : base.y;
+    F x2 = glv_phi_x(base.x);
+    F H = g_norm(g_sub(x2, base.x)), R = g_norm(g_sub(y2, y1));
+    F HH = g_sqr(H), HHH = g_mul(H, HH);
+    AffP<F> p1{g_mul(base.x, HH), g_mul(y1, HHH), base.inf};
+    AffP<F> p2{g_mul(x2, HH), g_mul(y2, HHH), base.inf};
+    F X3 = g_norm(g_sub(g_sub(g_sqr(R), HHH), g_dbl(p1.x)));
+    AffP<F> p3{X3, g_norm(g_sub(g_mul(R, g_norm(g_sub(p1.x, X3))), p1.y)), base.inf};
     jac_set_inf(acc);
     int top = 159;
     while (top >= 0 && !(((s.k1[top >> 5] | s.k2[top >> 5]) >> (top & 31)) & 1)) top--;
@@ -204,6 +206,7 @@ template <class F> GPBC_INLINE void scalar_mul29_jac(JacP<F> &acc, const AffP<F>
             jac_add_mixed(acc, acc, t);
         }
     }
+    if (!acc.inf) acc.z = g_mul(acc.z, H);               // back from the curve scaled by H
 }
 template <class F> GPBC_INLINE void scalar_mul29(AffP<F> &out, const AffP<F> &base, const uint32_t k[8]) {
     JacP<F> acc;

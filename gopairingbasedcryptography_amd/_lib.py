@@ -4,7 +4,8 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libgpbc_bn254.so")
+# GPBC_LIB_PATH: load another build of the same C ABI (kernel-tuning experiments); default is the in-tree library
+LIB_PATH = os.environ.get("GPBC_LIB_PATH") or os.path.join(HERE, "libgpbc_bn254.so")
 
 EXPORTS = [
     "gpbc_init", "gpbc_shutdown", "gpbc_last_error", "gpbc_device_count", "gpbc_abi_version",

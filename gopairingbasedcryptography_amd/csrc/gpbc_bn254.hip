@@ -23,6 +23,13 @@ constexpr int BLOCK = 64;
 #define GPBC_WAVES_PER_SIMD 2
 #endif
 #define GPBC_KERNEL __global__ void __launch_bounds__(BLOCK, GPBC_WAVES_PER_SIMD)
+// G1 arithmetic is light enough on registers for three waves per SIMD (168 VGPRs): measured +12 % over two, while the Fp2 /
+// Fp12 kernels lose 15-75 % to the extra spills (profiles/r01_microbench_valu2.txt explains the gain: a wave issues
+// at most one VALU instruction per ~4.5 cycles, so the 2.4-cycle VOP2 glue only gets cheaper with more waves).
+#ifndef GPBC_WAVES_G1
+#define GPBC_WAVES_G1 3
+#endif
+#define GPBC_KERNEL_G1 __global__ void __launch_bounds__(BLOCK, GPBC_WAVES_G1)
 
 __device__ __forceinline__ bool g1_bytes_inf(const uint8_t *p) { return bytes_all_zero(p, 16); }
 __device__ __forceinline__ bool g2_bytes_inf(const uint8_t *p) { return bytes_all_zero(p, 32); }
@@ -135,7 +142,7 @@ __device__ __forceinline__ void g2_store_aff(uint8_t *p, const AffP<F2> &r) { f2
 #define GPBC_SMUL_K 1
 #endif
 constexpr int SMUL_K = GPBC_SMUL_K;
-GPBC_KERNEL k_g1_scalar_mul(const uint8_t *__restrict__ bases, int shared_base, const uint8_t *__restrict__ scalars, uint8_t *__restrict__ out, size_t n) {
+GPBC_KERNEL_G1 k_g1_scalar_mul(const uint8_t *__restrict__ bases, int shared_base, const uint8_t *__restrict__ scalars, uint8_t *__restrict__ out, size_t n) {
     size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     size_t T = (n + SMUL_K - 1) / SMUL_K;
     if (t >= T) return;
@@ -177,7 +184,7 @@ GPBC_KERNEL k_g2_scalar_mul(const uint8_t *__restrict__ bases, int shared_base, 
 }
 
 // one level of the point-sum tree: thread t adds in[t], in[t+n_out], in[t+2 n_out], ... -> out[t] (affine)
-GPBC_KERNEL k_g1_sum_level(const uint8_t *__restrict__ in, size_t n_in, uint8_t *__restrict__ out, size_t n_out) {
+GPBC_KERNEL_G1 k_g1_sum_level(const uint8_t *__restrict__ in, size_t n_in, uint8_t *__restrict__ out, size_t n_out) {
     size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (t >= n_out) return;
     JacP<Fe> acc;

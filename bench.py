@@ -200,6 +200,31 @@ def main():
                 d = float(tm.item())
             sec[name + "_scalar_mults_per_s"] = world * B / d
             sec[name + "_frac_of_valu_peak"] = nominal * MAC_PER_FP_MUL * B / d / 1e12 / PEAK_TMAC_PER_S
+        # wire formats: encode / decode rates of the same batch, HBM-resident
+        def rate(fn, *a, **kw):
+            fn(*a, **kw)
+            barrier()
+            t1 = time.perf_counter()
+            fn(*a, **kw)
+            barrier()
+            d = time.perf_counter() - t1
+            if use_dist:
+                tm = torch.tensor([d], dtype=torch.float64, device=dev)
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                d = float(tm.item())
+            return world * B / d
+        nw = min(B, 1 << 18)                              # the G2 subgroup check makes G2 decoding the slow one
+        Pw, Qw, gw = P[:nw].contiguous(), Q[:nw].contiguous(), gt[:nw].contiguous()
+        wire = {"batch": nw}
+        for name, X, m, u in (("g1", Pw, bn254.g1_marshal, bn254.g1_unmarshal), ("g2", Qw, bn254.g2_marshal, bn254.g2_unmarshal)):
+            comp, raw = m(X, compressed=True), m(X)
+            wire[name + "_marshal_per_s"] = rate(m, X) * nw / B
+            wire[name + "_compress_per_s"] = rate(m, X, compressed=True) * nw / B
+            wire[name + "_unmarshal_raw_per_s"] = rate(u, raw, elem_bytes=raw.shape[1]) * nw / B
+            wire[name + "_unmarshal_compressed_per_s"] = rate(u, comp, elem_bytes=comp.shape[1]) * nw / B
+        wire["gt_marshal_per_s"] = rate(bn254.gt_marshal, gw) * nw / B
+        wire["gt_unmarshal_per_s"] = rate(bn254.gt_unmarshal, bn254.gt_marshal(gw)) * nw / B
+        sec["wire"] = wire
         result["secondary"] = sec
     # ---- CPU baseline (rank 0, single-GPU run only)
     if rank == 0 and world == 1:

@@ -364,3 +364,89 @@ def fp_mul(a, b):
     out = np.empty((n, 32), dtype=np.uint8)
     _lib.check(lib.gpbc_fp_mul_batch(_ptr(a), _ptr(b), _sz(n), _ptr(out)))
     return out
+
+
+# --------------------------------------------------------------------------------------- wire formats
+# gnark Marshal()/RawBytes(), Bytes() and Unmarshal()/SetBytes() (reference serialization/serialization_curve.go:5-33,
+# ibe/gentry06_ibe/gentry06_ibe.go:322-324, hash/hash_from_gt.go:5-8), batched.  Encodings are rows of
+# 64 / 32 (G1), 128 / 64 (G2) and 384 (GT) big-endian canonical bytes.
+_WIRE = {"g1": (G1_BYTES, 64, 32), "g2": (G2_BYTES, 128, 64), "gt": (GT_BYTES, 384, 384)}
+
+
+def _marshal(kind, x, compressed):
+    _ensure_init()
+    lib = _lib.load()
+    mem, raw, comp = _WIRE[kind]
+    width = comp if compressed else raw
+    host = getattr(lib, "gpbc_%s_marshal_batch" % kind)
+    dev = getattr(lib, "gpbc_%s_marshal_batch_dev" % kind)
+    cflag = () if kind == "gt" else (ctypes.c_int(1 if compressed else 0),)
+    if _is_torch(x):
+        n = x.numel() // mem
+        out = _tnew(x, n, width)
+        _lib.check(dev(_tptr(x), _sz(n), *cflag, _tptr(out), _torch_stream()))
+        return out
+    x = _np(x, mem)
+    n = x.size // mem
+    out = np.empty((n, width), dtype=np.uint8)
+    _lib.check(host(_ptr(x), _sz(n), *cflag, _ptr(out)))
+    return out
+
+
+def _unmarshal(kind, buf, elem_bytes):
+    _ensure_init()
+    lib = _lib.load()
+    mem, raw, comp = _WIRE[kind]
+    if elem_bytes is None:
+        elem_bytes = raw
+    if elem_bytes not in (raw, comp):
+        raise ValueError("%s element size must be %d or %d" % (kind, comp, raw))
+    host = getattr(lib, "gpbc_%s_unmarshal_batch" % kind)
+    dev = getattr(lib, "gpbc_%s_unmarshal_batch_dev" % kind)
+    eb = () if kind == "gt" else (_sz(elem_bytes),)
+    if _is_torch(buf):
+        import torch
+        if buf.numel() % elem_bytes:
+            raise ValueError("buffer length %d is not a multiple of %d" % (buf.numel(), elem_bytes))
+        n = buf.numel() // elem_bytes
+        out = _tnew(buf, n, mem)
+        ok = torch.empty((n,), dtype=torch.uint8, device=buf.device)
+        _lib.check(dev(_tptr(buf), *eb, _sz(n), _tptr(out), _tptr(ok), _torch_stream()))
+        return out, ok
+    buf = _np(buf, elem_bytes)
+    n = buf.size // elem_bytes
+    out = np.empty((n, mem), dtype=np.uint8)
+    ok = np.empty((n,), dtype=np.uint8)
+    _lib.check(host(_ptr(buf), *eb, _sz(n), _ptr(out), _ptr(ok)))
+    return out, ok
+
+
+def g1_marshal(pts, compressed=False):
+    """G1Affine.Marshal() (64 B rows) or, compressed, G1Affine.Bytes() (32 B rows)."""
+    return _marshal("g1", pts, compressed)
+
+
+def g2_marshal(pts, compressed=False):
+    """G2Affine.Marshal() (128 B rows) or, compressed, G2Affine.Bytes() (64 B rows)."""
+    return _marshal("g2", pts, compressed)
+
+
+def gt_marshal(gt):
+    """GT.Marshal() = GT.Bytes(): 384 B rows, coefficients C1.B2.A1 ... C0.B0.A0."""
+    return _marshal("gt", gt, False)
+
+
+def g1_unmarshal(buf, elem_bytes=None):
+    """G1Affine.Unmarshal() on rows of `elem_bytes` (64 default, or 32): (points, ok).  ok[i] = 0 where gnark returns an
+    error (the point row is then zero); the reference drops that error, callers here should look at it."""
+    return _unmarshal("g1", buf, elem_bytes)
+
+
+def g2_unmarshal(buf, elem_bytes=None):
+    """G2Affine.Unmarshal() on rows of `elem_bytes` (128 default, or 64): (points, ok); includes the subgroup check."""
+    return _unmarshal("g2", buf, elem_bytes)
+
+
+def gt_unmarshal(buf):
+    """GT.Unmarshal(): (values, ok)."""
+    return _unmarshal("gt", buf, None)

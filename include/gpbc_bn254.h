@@ -33,6 +33,11 @@ extern "C" {
 #define GPBC_G2_BYTES 128
 #define GPBC_GT_BYTES 384
 #define GPBC_SCALAR_BYTES 32
+/* wire formats (big-endian canonical, gnark Marshal / Bytes) */
+#define GPBC_G1_RAW_BYTES 64
+#define GPBC_G1_COMPRESSED_BYTES 32
+#define GPBC_G2_RAW_BYTES 128
+#define GPBC_G2_COMPRESSED_BYTES 64
 
 typedef enum {
     GPBC_OK = 0,
@@ -110,6 +115,34 @@ int gpbc_gt_inverse_batch(const void *a, size_t n, void *out);
 int gpbc_gt_mul_batch_dev(const void *d_a, const void *d_b, size_t n, void *d_out, void *stream);
 int gpbc_gt_div_batch_dev(const void *d_a, const void *d_b, size_t n, void *d_out, void *stream);
 int gpbc_gt_inverse_batch_dev(const void *d_a, size_t n, void *d_out, void *stream);
+
+/* ---- wire formats ------------------------------------------------------------------------------
+ * Big-endian canonical (non-Montgomery) encodings of gnark-crypto ecc/bn254 marshal.go; the two top bits of the first byte
+ * select the form: 00 uncompressed (infinity = all zero), 01 compressed infinity, 10 / 11 compressed with the smaller /
+ * larger Y.  G2 order: X.A1, X.A0[, Y.A1, Y.A0]; GT order: C1.B2.A1 ... C0.B0.A0.
+ *
+ * (G1Affine|G2Affine).Marshal() = RawBytes() (compressed == 0) and .Bytes() (compressed != 0), GT.Marshal() = Bytes()
+ *   (serialization/serialization_curve.go:5-15; ibe/gentry06_ibe/gentry06_ibe.go:322-324; hash/hash_from_gt.go:5-8).
+ * in: n gnark structs; out: n encodings of 64/32 (G1), 128/64 (G2), 384 (GT) bytes.  Not in place. */
+int gpbc_g1_marshal_batch(const void *pts, size_t n, int compressed, void *out);
+int gpbc_g2_marshal_batch(const void *pts, size_t n, int compressed, void *out);
+int gpbc_gt_marshal_batch(const void *gt, size_t n, void *out);
+int gpbc_g1_marshal_batch_dev(const void *d_pts, size_t n, int compressed, void *d_out, void *stream);
+int gpbc_g2_marshal_batch_dev(const void *d_pts, size_t n, int compressed, void *d_out, void *stream);
+int gpbc_gt_marshal_batch_dev(const void *d_gt, size_t n, void *d_out, void *stream);
+/* (G1Affine|G2Affine|GT).Unmarshal() = SetBytes() (serialization/serialization_curve.go:17-33), n times: element i
+ * occupies in[i*elem_bytes, (i+1)*elem_bytes) with elem_bytes = 32|64 (G1), 64|128 (G2), 384 (GT).  As in gnark the
+ * form is read from the flag bits (a compressed encoding in the first half of a 64/128-byte slot is accepted, an
+ * uncompressed flag in a 32/64-byte slot is a short buffer).  ok_out[i] = 1 where gnark returns no error and 0 where it
+ * returns one — coordinate >= p, malformed infinity, no square root, point not on the curve / not in the order-r
+ * subgroup (G2: [r]Q != infinity) — and then the output element is all zero.  The reference ignores that error
+ * (serialization_curve.go:19,25,31); callers of this entry should not.  Not in place. */
+int gpbc_g1_unmarshal_batch(const void *in, size_t elem_bytes, size_t n, void *pts_out, uint8_t *ok_out);
+int gpbc_g2_unmarshal_batch(const void *in, size_t elem_bytes, size_t n, void *pts_out, uint8_t *ok_out);
+int gpbc_gt_unmarshal_batch(const void *in, size_t n, void *gt_out, uint8_t *ok_out);
+int gpbc_g1_unmarshal_batch_dev(const void *d_in, size_t elem_bytes, size_t n, void *d_pts_out, uint8_t *d_ok_out, void *stream);
+int gpbc_g2_unmarshal_batch_dev(const void *d_in, size_t elem_bytes, size_t n, void *d_pts_out, uint8_t *d_ok_out, void *stream);
+int gpbc_gt_unmarshal_batch_dev(const void *d_in, size_t n, void *d_gt_out, uint8_t *d_ok_out, void *stream);
 
 /* ---- field-level entry (kernel unit tests) ------------------------------------------------------ */
 int gpbc_fp_mul_batch(const void *a, const void *b, size_t n, void *out);

@@ -7,6 +7,7 @@
 //   new(G1Affine).ScalarMultiplicationBase(s)                   -> G1Affine().ScalarMultiplicationBase(s)
 //   new(GT).Exp(x, k) / Mul / Div / Inverse                     -> GT().Exp(x, k) ...
 //   bn254.Generators()                                          -> bn254::Generators()
+//   p.Marshal() / p.Bytes() / p.Unmarshal(buf)  (G1, G2, GT)    -> same names; Unmarshal throws where gnark errors
 //
 // Structs have gnark's in-memory layout (fp.Element = 4 LE u64 Montgomery limbs), so arrays of them are the ABI
 // buffers.  Scalars are `Scalar` = 32-byte little-endian plain integers (what the cgo shim makes of *big.Int).
@@ -46,6 +47,17 @@ struct G1Affine {
         return *this;
     }
     G1Affine &ScalarMultiplicationBase(const Scalar &s);
+    // wire formats (gnark marshal.go): RawBytes 64 B, Bytes 32 B compressed; Unmarshal = SetBytes, returns bytes read
+    std::vector<uint8_t> Marshal() const { std::vector<uint8_t> b(GPBC_G1_RAW_BYTES); check(gpbc_g1_marshal_batch(this, 1, 0, b.data())); return b; }
+    std::array<uint8_t, GPBC_G1_COMPRESSED_BYTES> Bytes() const { std::array<uint8_t, GPBC_G1_COMPRESSED_BYTES> b; check(gpbc_g1_marshal_batch(this, 1, 1, b.data())); return b; }
+    size_t Unmarshal(const std::vector<uint8_t> &buf) {
+        if (buf.size() < GPBC_G1_COMPRESSED_BYTES) throw std::invalid_argument("short buffer");
+        size_t eb = buf.size() >= GPBC_G1_RAW_BYTES ? GPBC_G1_RAW_BYTES : GPBC_G1_COMPRESSED_BYTES;
+        uint8_t ok = 0;
+        check(gpbc_g1_unmarshal_batch(buf.data(), eb, 1, this, &ok));
+        if (!ok) throw std::invalid_argument("invalid G1 encoding");
+        return (buf[0] & 0x80) || (buf[0] & 0xC0) == 0x40 ? GPBC_G1_COMPRESSED_BYTES : GPBC_G1_RAW_BYTES;
+    }
 };
 // host-side field negation p - y on Montgomery limbs (gnark's G1Affine.Neg / G2Affine.Neg; not a hot-path operation)
 inline fpElement fpNeg(const fpElement &y) {
@@ -69,6 +81,16 @@ struct G2Affine {
         return *this;
     }
     G2Affine &ScalarMultiplicationBase(const Scalar &s);
+    std::vector<uint8_t> Marshal() const { std::vector<uint8_t> b(GPBC_G2_RAW_BYTES); check(gpbc_g2_marshal_batch(this, 1, 0, b.data())); return b; }
+    std::array<uint8_t, GPBC_G2_COMPRESSED_BYTES> Bytes() const { std::array<uint8_t, GPBC_G2_COMPRESSED_BYTES> b; check(gpbc_g2_marshal_batch(this, 1, 1, b.data())); return b; }
+    size_t Unmarshal(const std::vector<uint8_t> &buf) {          // includes gnark's subgroup check
+        if (buf.size() < GPBC_G2_COMPRESSED_BYTES) throw std::invalid_argument("short buffer");
+        size_t eb = buf.size() >= GPBC_G2_RAW_BYTES ? GPBC_G2_RAW_BYTES : GPBC_G2_COMPRESSED_BYTES;
+        uint8_t ok = 0;
+        check(gpbc_g2_unmarshal_batch(buf.data(), eb, 1, this, &ok));
+        if (!ok) throw std::invalid_argument("invalid G2 encoding");
+        return (buf[0] & 0x80) || (buf[0] & 0xC0) == 0x40 ? GPBC_G2_COMPRESSED_BYTES : GPBC_G2_RAW_BYTES;
+    }
 };
 struct GT {
     E2 c[6]{};   // C0.B0, C0.B1, C0.B2, C1.B0, C1.B1, C1.B2
@@ -77,6 +99,14 @@ struct GT {
     GT &Mul(const GT &a, const GT &b) { check(gpbc_gt_mul_batch(&a, &b, 1, this)); return *this; }
     GT &Div(const GT &a, const GT &b) { check(gpbc_gt_div_batch(&a, &b, 1, this)); return *this; }
     GT &Inverse(const GT &a) { check(gpbc_gt_inverse_batch(&a, 1, this)); return *this; }
+    std::array<uint8_t, GPBC_GT_BYTES> Bytes() const { std::array<uint8_t, GPBC_GT_BYTES> b; check(gpbc_gt_marshal_batch(this, 1, b.data())); return b; }
+    std::vector<uint8_t> Marshal() const { auto b = Bytes(); return std::vector<uint8_t>(b.begin(), b.end()); }
+    void Unmarshal(const std::vector<uint8_t> &buf) {
+        if (buf.size() < GPBC_GT_BYTES) throw std::invalid_argument("short buffer");
+        uint8_t ok = 0;
+        check(gpbc_gt_unmarshal_batch(buf.data(), 1, this, &ok));
+        if (!ok) throw std::invalid_argument("invalid GT encoding");
+    }
 };
 static_assert(sizeof(G1Affine) == GPBC_G1_BYTES && sizeof(G2Affine) == GPBC_G2_BYTES && sizeof(GT) == GPBC_GT_BYTES, "gnark layouts");
 

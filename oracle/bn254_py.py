@@ -334,6 +334,157 @@ def gt_to_canonical_bytes(a):
     return b"".join(x.to_bytes(32, "big") for x in reversed(flat))
 
 
+# ----------------------------------------------------------------------------- wire formats
+# gnark-crypto ecc/bn254 marshal.go as published [EXT, parity unpinned]: big-endian canonical (non-Montgomery)
+# coordinates; the two most significant bits of the first byte carry the form (p < 2^254 leaves them free):
+#   00 uncompressed (X || Y; the point at infinity is all zero)     10 compressed, Y is the smaller of {Y, -Y}
+#   01 compressed infinity (rest zero)                              11 compressed, Y is the larger
+# G2 writes X.A1 || X.A0 [|| Y.A1 || Y.A0].  "Larger" = LexicographicallyLargest: for Fp y > (p-1)/2; for Fp2 the
+# test is made on A1 unless A1 = 0, then on A0.  Reference call sites: serialization/serialization_curve.go:5-33
+# (Marshal / Unmarshal), ibe/gentry06_ibe/gentry06_ibe.go:322-324 (G1 Bytes, GT Bytes), hash/hash_from_gt.go:5-8.
+M_MASK, M_UNCOMPRESSED, M_INFINITY, M_SMALLEST, M_LARGEST = 0xC0, 0x00, 0x40, 0x80, 0xC0
+
+def fp_lex_largest(y): return y > (P - 1) // 2
+def f2_lex_largest(y): return fp_lex_largest(y[1]) if y[1] != 0 else fp_lex_largest(y[0])
+
+def fp_sqrt(a):
+    """A square root of a in Fp (p = 3 mod 4) or None."""
+    y = pow(a, (P + 1) // 4, P)
+    return y if y * y % P == a % P else None
+
+def f2_sqrt(a):
+    """A square root of a in Fp2 or None (norm method; either root may be returned, callers fix the sign)."""
+    a0, a1 = a[0] % P, a[1] % P
+    if a1 == 0:
+        y = fp_sqrt(a0)
+        if y is not None:
+            return (y, 0)
+        y = fp_sqrt((-a0) % P)               # sqrt(-|a0|) = i sqrt(|a0|)
+        return None if y is None else (0, y)
+    n = fp_sqrt((a0 * a0 + a1 * a1) % P)
+    if n is None:
+        return None
+    half = pow(2, -1, P)
+    t = (a0 + n) * half % P
+    x0 = fp_sqrt(t)
+    if x0 is None:
+        t = (a0 - n) * half % P
+        x0 = fp_sqrt(t)
+        if x0 is None:
+            return None
+    x1 = a1 * pow(2 * x0, -1, P) % P
+    r = (x0, x1)
+    return r if f2_sqr(r) == (a0, a1) else None
+
+def g1_marshal(pt, compressed=False):
+    """G1Affine.Marshal()/RawBytes() (64 B) or Bytes() (32 B)."""
+    if compressed:
+        if pt is None:
+            return bytes([M_INFINITY]) + bytes(31)
+        b = bytearray(pt[0].to_bytes(32, "big"))
+        b[0] |= M_LARGEST if fp_lex_largest(pt[1]) else M_SMALLEST
+        return bytes(b)
+    if pt is None:
+        return bytes(64)
+    return pt[0].to_bytes(32, "big") + pt[1].to_bytes(32, "big")
+
+def g2_marshal(pt, compressed=False):
+    if compressed:
+        if pt is None:
+            return bytes([M_INFINITY]) + bytes(63)
+        b = bytearray(pt[0][1].to_bytes(32, "big") + pt[0][0].to_bytes(32, "big"))
+        b[0] |= M_LARGEST if f2_lex_largest(pt[1]) else M_SMALLEST
+        return bytes(b)
+    if pt is None:
+        return bytes(128)
+    return b"".join(v.to_bytes(32, "big") for v in (pt[0][1], pt[0][0], pt[1][1], pt[1][0]))
+
+def g2_in_subgroup(pt):
+    return pt is None or (g2_is_on_curve(pt) and g2_mul_plain(pt, R) is None)
+
+def g2_mul_plain(a, k):
+    """double-and-add without reducing k mod r (the point may lie outside the order-r subgroup)."""
+    acc = None
+    for bit in bin(k)[2:]:
+        acc = g2_add(acc, acc)
+        if bit == "1":
+            acc = g2_add(acc, a)
+    return acc
+
+def g1_unmarshal(buf):
+    """G1Affine.SetBytes on one element buffer (32 or 64 B): (point, ok).  ok = False where gnark returns an error
+    (short buffer, non-canonical coordinate, bad infinity encoding, no square root, not on the curve)."""
+    if len(buf) < 32:
+        return None, False
+    flag = buf[0] & M_MASK
+    if flag == M_UNCOMPRESSED:
+        if len(buf) < 64:
+            return None, False
+        x, y = int.from_bytes(buf[0:32], "big"), int.from_bytes(buf[32:64], "big")
+        if x >= P or y >= P:
+            return None, False
+        if x == 0 and y == 0:
+            return None, True
+        return ((x, y), True) if g1_is_on_curve((x, y)) else (None, False)
+    if flag == M_INFINITY:
+        ok = (buf[0] & ~M_MASK & 0xFF) == 0 and not any(buf[1:32])
+        return None, ok
+    x = int.from_bytes(bytes([buf[0] & ~M_MASK & 0xFF]) + bytes(buf[1:32]), "big")
+    if x >= P:
+        return None, False
+    y = fp_sqrt((x * x * x + B_G1) % P)
+    if y is None:
+        return None, False
+    if fp_lex_largest(y) != (flag == M_LARGEST):
+        y = (-y) % P
+    return (x, y), True
+
+def g2_unmarshal(buf):
+    """G2Affine.SetBytes on one element buffer (64 or 128 B): (point, ok); includes the subgroup check."""
+    if len(buf) < 64:
+        return None, False
+    flag = buf[0] & M_MASK
+    rd = lambda i: int.from_bytes(buf[32 * i:32 * i + 32], "big")
+    if flag == M_UNCOMPRESSED:
+        if len(buf) < 128:
+            return None, False
+        x1, x0, y1, y0 = rd(0), rd(1), rd(2), rd(3)
+        if max(x1, x0, y1, y0) >= P:
+            return None, False
+        if x0 == x1 == y0 == y1 == 0:
+            return None, True
+        pt = ((x0, x1), (y0, y1))
+        return (pt, True) if g2_in_subgroup(pt) else (None, False)
+    if flag == M_INFINITY:
+        ok = (buf[0] & ~M_MASK & 0xFF) == 0 and not any(buf[1:64])
+        return None, ok
+    x1 = int.from_bytes(bytes([buf[0] & ~M_MASK & 0xFF]) + bytes(buf[1:32]), "big")
+    x0 = rd(1)
+    if x1 >= P or x0 >= P:
+        return None, False
+    x = (x0, x1)
+    y = f2_sqrt(f2_add(f2_mul(f2_sqr(x), x), B_G2))
+    if y is None:
+        return None, False
+    if f2_lex_largest(y) != (flag == M_LARGEST):
+        y = f2_neg(y)
+    pt = (x, y)
+    return (pt, True) if g2_in_subgroup(pt) else (None, False)
+
+def gt_marshal(a): return gt_to_canonical_bytes(a)
+
+def gt_unmarshal(buf):
+    """GT.SetBytes: 12 canonical big-endian coefficients, C1.B2.A1 first; (value, ok)."""
+    if len(buf) < 384:
+        return None, False
+    vals = [int.from_bytes(buf[32 * i:32 * i + 32], "big") for i in range(12)]
+    if max(vals) >= P:
+        return None, False
+    flat = list(reversed(vals))                       # C0.B0.A0, C0.B0.A1, ..., C1.B2.A1
+    cs = [(flat[2 * i], flat[2 * i + 1]) for i in range(6)]
+    return ((cs[0], cs[1], cs[2]), (cs[3], cs[4], cs[5])), True
+
+
 # ----------------------------------------------------------------------------- deterministic synthetic inputs
 SEED = 0x424E323534
 

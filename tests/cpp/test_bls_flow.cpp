@@ -57,6 +57,24 @@ int main() {
     bool threw = false;
     try { Pair({g1, g1}, {g2}); } catch (const std::invalid_argument &) { threw = true; }
     EXPECT(threw);                                               // "invalid inputs sizes"
+    // wire formats: Marshal / Bytes / Unmarshal round trips (reference serialization/serialization_curve.go:5-33)
+    {
+        G1Affine back; G2Affine back2; GT backt;
+        EXPECT(back.Unmarshal(a.pk.Marshal()) == 64 && back.Equal(a.pk));
+        auto c = a.pk.Bytes();
+        EXPECT(back.Unmarshal(std::vector<uint8_t>(c.begin(), c.end())) == 32 && back.Equal(a.pk));
+        EXPECT(back2.Unmarshal(sig.Marshal()) == 128 && back2.Equal(sig));
+        auto c2 = sig.Bytes();
+        EXPECT(back2.Unmarshal(std::vector<uint8_t>(c2.begin(), c2.end())) == 64 && back2.Equal(sig));
+        backt.Unmarshal(e.Marshal());
+        EXPECT(backt.Equal(e));
+        auto g1c = g1.Bytes();                                   // (1, 2): smaller-Y flag, x = 1
+        EXPECT(g1c[0] == 0x80 && g1c[31] == 1);
+        std::vector<uint8_t> bad(64, 0); bad[31] = 1; bad[63] = 3;   // (1, 3) is not on the curve
+        bool rejected = false;
+        try { back.Unmarshal(bad); } catch (const std::invalid_argument &) { rejected = true; }
+        EXPECT(rejected);
+    }
     printf("BLS flow OK\n");
     return 0;
 }

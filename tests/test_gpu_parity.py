@@ -318,3 +318,79 @@ def test_afp25_batched_decrypt_on_gpu(eng, oracle):
     for t, item in enumerate(inst.items):
         assert (out[t] == inst.msgs[t]).all()
         assert (out[t] == inst.reference_shaped_decrypt(oracle, item)).all()
+
+
+# ---------------------------------------------------------------------------------------- wire formats (§8 f-4)
+def test_wire_golden(eng):
+    g = load_golden("wire.json")
+    for key, marshal, unmarshal in (("g1", eng.g1_marshal, eng.g1_unmarshal), ("g2", eng.g2_marshal, eng.g2_unmarshal)):
+        cs = g[key]
+        mem = cat([c["mem"] for c in cs])
+        for comp, field in ((False, "raw"), (True, "compressed")):
+            enc = marshal(mem, compressed=comp)
+            for i, c in enumerate(cs):
+                assert enc[i].tobytes().hex() == c[field], (key, field, c["note"])
+            dec, ok = unmarshal(cat([c[field] for c in cs]), elem_bytes=enc.shape[1])
+            assert ok.all() and dec.tobytes() == mem.tobytes(), (key, field)
+        for c in g["decode_" + key]:
+            dec, ok = unmarshal(hx(c["wire"]), elem_bytes=c["elem_bytes"])
+            assert int(ok[0]) == c["ok"] and dec[0].tobytes().hex() == c["mem"], (key, c["note"])
+    cs = g["gt"]
+    mem = cat([c["mem"] for c in cs])
+    assert eng.gt_marshal(mem).tobytes().hex() == "".join(c["wire"] for c in cs)
+    dec, ok = eng.gt_unmarshal(cat([c["wire"] for c in cs]))
+    assert ok.all() and dec.tobytes() == mem.tobytes()
+    for c in g["decode_gt"]:
+        dec, ok = eng.gt_unmarshal(hx(c["wire"]))
+        assert int(ok[0]) == c["ok"] and dec[0].tobytes().hex() == c["mem"], c["note"]
+    with pytest.raises(ValueError):
+        eng.g1_unmarshal(np.zeros(48, dtype=np.uint8), elem_bytes=48)
+
+
+def test_wire_vs_oracle_and_corruption(eng, synth):
+    """Engine encodings of the synthetic points against the big-integer oracle, then bit flips: the engine and the oracle
+    must accept / reject the same buffers and agree on every accepted point."""
+    P, Q = synth
+    n = 24
+    rng = np.random.default_rng(99)
+    for pts, w, marshal, unmarshal, from_mem, to_mem, o_marshal, o_unmarshal in (
+            (P, 64, eng.g1_marshal, eng.g1_unmarshal, o.g1_from_bytes, o.g1_to_bytes, o.g1_marshal, o.g1_unmarshal),
+            (Q, 128, eng.g2_marshal, eng.g2_unmarshal, o.g2_from_bytes, o.g2_to_bytes, o.g2_marshal, o.g2_unmarshal)):
+        pts = np.ascontiguousarray(pts[:n])
+        for comp in (False, True):
+            enc = marshal(pts, compressed=comp)
+            for i in range(n):
+                assert enc[i].tobytes() == o_marshal(from_mem(pts[i].tobytes()), comp), (w, comp, i)
+            bad = enc.copy()
+            for i in range(n):
+                for _ in range(int(rng.integers(1, 3))):
+                    bad[i, int(rng.integers(0, bad.shape[1]))] ^= np.uint8(1 << int(rng.integers(0, 8)))
+            dec, ok = unmarshal(bad, elem_bytes=bad.shape[1])
+            for i in range(n):
+                pt, good = o_unmarshal(bad[i].tobytes())
+                assert int(good) == int(ok[i]), (w, comp, i)
+                assert dec[i].tobytes() == to_mem(pt if good else None), (w, comp, i)
+
+
+def test_wire_round_trip_large_device_path(eng):
+    """Size-independent property at a large batch, HBM-resident: unmarshal(marshal(X)) == X with every ok flag set, for
+    both forms; compressed and uncompressed forms decode to the same points; GT through e(P_i, Q_i)."""
+    import torch
+    n = 1 << 14
+    g1, g2 = eng.generators()
+    P = torch.from_numpy(eng.g1_scalar_mul(g1, scalars("wP", n))).cuda()
+    Q = torch.from_numpy(eng.g2_scalar_mul(g2, scalars("wQ", n))).cuda()
+    P[5].zero_()
+    Q[9].zero_()                                         # infinity rows
+    for X, marshal, unmarshal, raw_w in ((P, eng.g1_marshal, eng.g1_unmarshal, 64), (Q, eng.g2_marshal, eng.g2_unmarshal, 128)):
+        raw, comp = marshal(X), marshal(X, compressed=True)
+        assert raw.shape == (n, raw_w) and comp.shape == (n, raw_w // 2)
+        for enc in (raw, comp):
+            back, ok = unmarshal(enc, elem_bytes=enc.shape[1])
+            assert bool(ok.all()) and torch.equal(back, X)
+        assert int((comp[:, 0] >> 6).min()) >= 1          # every compressed row carries a flag
+    m = 2048
+    gt = eng.pair_batch(P[:m].contiguous(), Q[:m].contiguous())
+    back, ok = eng.gt_unmarshal(eng.gt_marshal(gt))
+    assert bool(ok.all()) and torch.equal(back, gt)
+    assert eng.gt_marshal(gt)[5].cpu().numpy().tobytes() == bytes(383) + b"\x01"      # e(inf, Q) = 1

@@ -11,6 +11,7 @@
 #include "../gopairingbasedcryptography_amd/csrc/curve29.cuh"
 #include "../gopairingbasedcryptography_amd/csrc/pairing29.cuh"
 #include "../gopairingbasedcryptography_amd/csrc/pairing29_pair.cuh"
+#include "../gopairingbasedcryptography_amd/csrc/wire29.cuh"
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -162,6 +163,21 @@ void hc_gt_pair_ops(const uint8_t *A, const uint8_t *B, size_t n, uint8_t *mul, 
 }
 // worst-case figures since process start: [max |int64 column|, max limb bound, max value bound (units of p),
 // #products (fe_mul + fe_mul2), #norms, #fe_mul2, #reduces]  (out must hold 7 doubles)
+// wire formats (csrc/wire29.cuh): kind 0 G1, 1 G2, 2 GT; the same per-element functions the kernels call
+void hc_wire_encode(int kind, const uint8_t *in, size_t n, int compressed, uint8_t *out) {
+    for (size_t i = 0; i < n; i++) {
+        if (kind == 0) g1_wire_encode(out + i * (compressed ? 32 : 64), in + 64 * i, compressed != 0);
+        else if (kind == 1) g2_wire_encode(out + i * (compressed ? 64 : 128), in + 128 * i, compressed != 0);
+        else gt_wire_encode(out + 384 * i, in + 384 * i);
+    }
+}
+void hc_wire_decode(int kind, const uint8_t *in, int elem_bytes, size_t n, uint8_t *out, uint8_t *ok) {
+    for (size_t i = 0; i < n; i++) {
+        if (kind == 0) ok[i] = g1_wire_decode(out + 64 * i, in + (size_t)elem_bytes * i, elem_bytes);
+        else if (kind == 1) ok[i] = g2_wire_decode(out + 128 * i, in + (size_t)elem_bytes * i, elem_bytes);
+        else ok[i] = gt_wire_decode(out + 384 * i, in + 384 * i);
+    }
+}
 void hc_stats(double *out) {
     stats_flush();
     BoundStats &s = g_stats_total;

@@ -225,6 +225,8 @@ def main():
         wire["gt_marshal_per_s"] = rate(bn254.gt_marshal, gw) * nw / B
         wire["gt_unmarshal_per_s"] = rate(bn254.gt_unmarshal, bn254.gt_marshal(gw)) * nw / B
         sec["wire"] = wire
+        ne = min(B, 1 << 16)                              # GT.Exp by full-size exponents
+        sec["gt_exp_per_s"] = rate(bn254.gt_exp, gt[:ne].contiguous(), ks[:ne].contiguous()) * ne / B
         result["secondary"] = sec
     # ---- CPU baseline (rank 0, single-GPU run only)
     if rank == 0 and world == 1:

@@ -208,23 +208,14 @@ GPBC_KERNEL k_g2_sum_level(const uint8_t *__restrict__ in, size_t n_in, uint8_t 
 
 // GT.Exp: left-to-right square-and-multiply on a 256-bit plain exponent (k = 0 -> one)
 GPBC_KERNEL k_gt_exp(const uint8_t *__restrict__ x, const uint8_t *__restrict__ kk, uint8_t *__restrict__ out, size_t n) {
-    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    size_t lane = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    size_t i = lane >> 1;                                   // one Fp12 per lane pair
     if (i >= n) return;
-    F12 b, r;
-    f12_load(b, x + i * GPBC_GT_BYTES);
+    PairDpp px{(bool)(lane & 1)};
+    size_t off = i * GPBC_GT_BYTES + (px.odd ? 192 : 0);
     uint32_t k[8];
     load_scalar(k, kk + i * GPBC_SCALAR_BYTES);
-    int top = 255;
-    while (top >= 0 && !((k[top >> 5] >> (top & 31)) & 1)) top--;
-    if (top < 0) r = f12_one();
-    else {
-        r = b;
-        for (int j = top - 1; j >= 0; j--) {
-            r = f12_sqr(r);
-            if ((k[j >> 5] >> (j & 31)) & 1) r = f12_mul(r, b);
-        }
-    }
-    f12_store(out + i * GPBC_GT_BYTES, r);
+    f6_store(out + off, f12p_exp256(px, f6_load(x + off), k));
 }
 
 // op 0: a*b   1: a*b^-1   2: a^-1
@@ -484,7 +475,7 @@ int gpbc_gt_exp_batch_dev(const void *d_x, const void *d_k, size_t n, void *d_ou
     if (!n) return GPBC_OK;
     if (!d_x || !d_k || !d_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
     TRY(bind_device());
-    k_gt_exp<<<grid_for(n), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_x, (const uint8_t *)d_k, (uint8_t *)d_out, n);
+    k_gt_exp<<<grid_for(2 * n), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_x, (const uint8_t *)d_k, (uint8_t *)d_out, n);
     return check_launch("k_gt_exp");
 }
 static int gt_binary_dev(int op, const void *a, const void *b, size_t n, void *out, void *stream) {

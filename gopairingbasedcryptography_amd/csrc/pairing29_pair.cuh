@@ -87,6 +87,22 @@ template <class X> GPBC_INLINE F6 final_exp_pair(const X &x, const F6 &in) {
     return f12p_mul(x, t2, t0);
 }
 
+// b^k for a 256-bit k (GT.Exp: generic squarings, so any Fp12 element is handled, not only the cyclotomic subgroup;
+// no reduction of k): fixed 4-bit windows, left to right, table b^0..b^15 in private memory.
+template <class X> GPBC_NOINLINE F6 f12p_exp256(const X &x, const F6 &b, const uint32_t (&k)[8]) {
+    F6 tab[16];
+    tab[0] = f12p_one(x);
+    tab[1] = b;
+    for (int i = 2; i < 16; i++) tab[i] = f12p_mul(x, tab[i - 1], b);
+    F6 r = tab[(k[7] >> 28) & 15];
+    for (int w = 62; w >= 0; w--) {
+        for (int s = 0; s < 4; s++) r = f6_reduce(f12p_sqr(x, r));
+        int d = (k[w >> 3] >> (4 * (w & 7))) & 15;
+        r = f12p_mul(x, r, tab[d]);                         // d = 0 multiplies by one: no divergence inside the pair or the wave
+    }
+    return r;
+}
+
 GPBC_INLINE F6 f6_load(const uint8_t *p) { return F6{f2_load(p), f2_load(p + 64), f2_load(p + 128)}; }
 GPBC_INLINE void f6_store(uint8_t *p, const F6 &z) { f2_store(p, z.b0); f2_store(p + 64, z.b1); f2_store(p + 128, z.b2); }
 

@@ -21,7 +21,7 @@ SO = os.path.join(ROOT, "tools", "libgpbc_bounds.so")
 def hc():
     src = os.path.join(ROOT, "tools", "bounds_check.cpp")
     hdrs = [os.path.join(ROOT, "gopairingbasedcryptography_amd", "csrc", f)
-            for f in ("fe29.cuh", "tower29.cuh", "tower29_pair.cuh", "curve29.cuh", "pairing29.cuh", "pairing29_pair.cuh")]
+            for f in ("fe29.cuh", "tower29.cuh", "tower29_pair.cuh", "curve29.cuh", "pairing29.cuh", "pairing29_pair.cuh", "wire29.cuh")]
     if not os.path.exists(SO) or any(os.path.getmtime(f) > os.path.getmtime(SO) for f in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-pthread", "-std=c++17", "-DGPBC_BOUNDS", "-shared", "-fPIC", "-o", SO, src])
     return ctypes.CDLL(SO)
@@ -132,3 +132,21 @@ def test_glv_split_identity(hc):
         k1 = sum(int(row[i]) << (32 * i) for i in range(5)) * (-1 if row[10] else 1)
         k2 = sum(int(row[5 + i]) << (32 * i) for i in range(5)) * (-1 if row[11] else 1)
         assert (k1 + k2 * lam - k) % o.R == 0 and abs(k1).bit_length() <= 130 and abs(k2).bit_length() <= 130
+
+
+def test_gt_exp_pair_under_bounds(hc):
+    """k_gt_exp's lane-pair windowed exponentiation (generic squarings): pairing values and random Fp12 elements, edge
+    exponents 0, 1, 15, 16, r-1, 2^256-1."""
+    import random
+    random.seed(3)
+    e = o.pair([o.G1_GEN], [o.G2_GEN])
+    rnd = lambda: tuple(tuple((random.randrange(o.P), random.randrange(o.P)) for _ in range(3)) for _ in range(2))
+    A, K, exp = [], [], []
+    for x, ks in ((e, [0, 1, 2, 15, 16, o.R - 1, (1 << 256) - 1, random.randrange(1 << 256)]), (rnd(), [3, random.randrange(1 << 256)])):
+        for k in ks:
+            A.append(o.gt_to_bytes(x)); K.append(k.to_bytes(32, "little")); exp.append(o.gt_to_bytes(o.f12_pow(x, k)))
+    a = np.frombuffer(b"".join(A), dtype=np.uint8).copy()
+    k = np.frombuffer(b"".join(K), dtype=np.uint8).copy()
+    out = np.zeros(len(A) * 384, dtype=np.uint8)
+    hc.hc_gt_exp_pair(vp(a), vp(k), ctypes.c_size_t(len(A)), vp(out))
+    assert out.tobytes() == b"".join(exp)

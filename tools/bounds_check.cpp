@@ -161,8 +161,22 @@ void hc_gt_pair_ops(const uint8_t *A, const uint8_t *B, size_t n, uint8_t *mul, 
         t1.join();
     }
 }
-// worst-case figures since process start: [max |int64 column|, max limb bound, max value bound (units of p),
-// #products (fe_mul + fe_mul2), #norms, #fe_mul2, #reduces]  (out must hold 7 doubles)
+// GT.Exp on a lane pair (k_gt_exp): out = a^k for 256-bit little-endian k
+void hc_gt_exp_pair(const uint8_t *A, const uint8_t *K, size_t n, uint8_t *out) {
+    for (size_t i = 0; i < n; i++) {
+        PairRendezvous rv;
+        uint32_t k[8]; memcpy(k, K + 32 * i, 32);
+        auto lane = [&](bool odd) {
+            PairHost x{odd, &rv};
+            size_t o = 384 * i + (odd ? 192 : 0);
+            f6_store(out + o, f12p_exp256(x, f6_load(A + o), k));
+            stats_flush();
+        };
+        std::thread t1(lane, true);
+        lane(false);
+        t1.join();
+    }
+}
 // wire formats (csrc/wire29.cuh): kind 0 G1, 1 G2, 2 GT; the same per-element functions the kernels call
 void hc_wire_encode(int kind, const uint8_t *in, size_t n, int compressed, uint8_t *out) {
     for (size_t i = 0; i < n; i++) {
@@ -178,6 +192,8 @@ void hc_wire_decode(int kind, const uint8_t *in, int elem_bytes, size_t n, uint8
         else ok[i] = gt_wire_decode(out + 384 * i, in + 384 * i);
     }
 }
+// worst-case figures since process start: [max |int64 column|, max limb bound, max value bound (units of p),
+// #products (fe_mul + fe_mul2), #norms, #fe_mul2, #reduces]  (out must hold 7 doubles)
 void hc_stats(double *out) {
     stats_flush();
     BoundStats &s = g_stats_total;

@@ -9,7 +9,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgpbc_bn254.so")
 STAMP = os.path.join(HERE, "libgpbc_bn254.buildhash")
 SOURCES = ["gpbc_bn254.hip"]
-HEADERS = ["fe29.cuh", "tower29.cuh", "tower29_pair.cuh", "curve29.cuh", "pairing29.cuh", "pairing29_pair.cuh", "wire29.cuh", "bn254_constants.cuh", "bn254_constants29.cuh"]
+HEADERS = ["fe29.cuh", "tower29.cuh", "tower29_pair.cuh", "curve29.cuh", "pairing29.cuh", "pairing29_pair.cuh", "wire29.cuh", "h2c29.cuh", "bn254_constants.cuh", "bn254_constants29.cuh"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC"]
 
 

@@ -22,6 +22,8 @@ EXPORTS = [
     "gpbc_g1_marshal_batch_dev", "gpbc_g2_marshal_batch_dev", "gpbc_gt_marshal_batch_dev",
     "gpbc_g1_unmarshal_batch", "gpbc_g2_unmarshal_batch", "gpbc_gt_unmarshal_batch",
     "gpbc_g1_unmarshal_batch_dev", "gpbc_g2_unmarshal_batch_dev", "gpbc_gt_unmarshal_batch_dev",
+    "gpbc_g1_map_to_curve_batch", "gpbc_g2_map_to_curve_batch",
+    "gpbc_g1_map_to_curve_batch_dev", "gpbc_g2_map_to_curve_batch_dev",
 ]
 
 _lib = None

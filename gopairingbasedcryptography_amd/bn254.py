@@ -450,3 +450,31 @@ def g2_unmarshal(buf, elem_bytes=None):
 def gt_unmarshal(buf):
     """GT.Unmarshal(): (values, ok)."""
     return _unmarshal("gt", buf, None)
+
+
+# --------------------------------------------------------------------------------------- hash to curve, group part
+def _map_fields(width, host_fn, dev_fn, u):
+    _ensure_init()
+    lib = _lib.load()
+    if _is_torch(u):
+        n = u.numel() // width
+        out = _tnew(u, n, width)
+        _lib.check(dev_fn(_tptr(u), _sz(n), _tptr(out), _torch_stream()))
+        return out
+    u = _np(u, width)
+    n = u.size // width
+    out = np.empty((n, width), dtype=np.uint8)
+    _lib.check(host_fn(_ptr(u), _sz(n), _ptr(out)))
+    return out
+
+
+def map_to_g1(u):
+    """Tail of bn254.HashToG1: rows of two fp.Element (64 B, gnark layout) -> MapToCurve1(u0) + MapToCurve1(u1)."""
+    lib = _lib.load()
+    return _map_fields(G1_BYTES, lib.gpbc_g1_map_to_curve_batch, lib.gpbc_g1_map_to_curve_batch_dev, u)
+
+
+def map_to_g2(u):
+    """Tail of bn254.HashToG2: rows of two E2 (128 B) -> ClearCofactor(MapToCurve2(u0) + MapToCurve2(u1))."""
+    lib = _lib.load()
+    return _map_fields(G2_BYTES, lib.gpbc_g2_map_to_curve_batch, lib.gpbc_g2_map_to_curve_batch_dev, u)

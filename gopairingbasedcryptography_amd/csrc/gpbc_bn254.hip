@@ -13,6 +13,7 @@
 #include "pairing29.cuh"
 #include "pairing29_pair.cuh"
 #include "wire29.cuh"
+#include "h2c29.cuh"
 
 using namespace gpbc;
 
@@ -271,6 +272,22 @@ GPBC_KERNEL k_gt_decode(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
     ok[i] = gt_wire_decode(out + i * GPBC_GT_BYTES, in + i * GPBC_GT_BYTES) ? 1 : 0;
 }
 
+// ---- hash to curve, group part (csrc/h2c29.cuh): u = n x 2 field elements -> n points
+GPBC_KERNEL k_g1_map_fields(const uint8_t *__restrict__ u, uint8_t *__restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    AffP<Fe> r;
+    g1_map_fields(r, fe_load(u + i * 64), fe_load(u + i * 64 + 32));
+    g1_store_aff(out + i * GPBC_G1_BYTES, r);
+}
+GPBC_KERNEL k_g2_map_fields(const uint8_t *__restrict__ u, uint8_t *__restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    AffP<F2> r;
+    g2_map_fields(r, f2_load(u + i * 128), f2_load(u + i * 128 + 64));
+    g2_store_aff(out + i * GPBC_G2_BYTES, r);
+}
+
 // =============================================================================================== host side
 static thread_local char g_err[512] = "";
 static std::atomic<int> g_device{-1};
@@ -322,7 +339,7 @@ struct DevBuf {
 
 extern "C" {
 
-int gpbc_abi_version(void) { return 2; }
+int gpbc_abi_version(void) { return 3; }
 const char *gpbc_last_error(void) { return g_err; }
 
 int gpbc_device_count(void) {
@@ -718,5 +735,30 @@ int gpbc_gt_unmarshal_batch(const void *in, size_t n, void *o, uint8_t *ok) { re
 int gpbc_g1_unmarshal_batch_dev(const void *in, size_t eb, size_t n, void *o, uint8_t *ok, void *st) { return unmarshal_dev(0, in, eb, n, o, ok, st); }
 int gpbc_g2_unmarshal_batch_dev(const void *in, size_t eb, size_t n, void *o, uint8_t *ok, void *st) { return unmarshal_dev(1, in, eb, n, o, ok, st); }
 int gpbc_gt_unmarshal_batch_dev(const void *in, size_t n, void *o, uint8_t *ok, void *st) { return unmarshal_dev(2, in, GPBC_GT_BYTES, n, o, ok, st); }
+
+// ----------------------------------------------------------------------------------------------- hash to curve (group part)
+static int map_fields_dev(bool g2, const void *d_u, size_t n, void *d_out, void *stream) {
+    if (!n) return GPBC_OK;
+    if (!d_u || !d_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    TRY(bind_device());
+    if (g2) k_g2_map_fields<<<grid_for(n), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_u, (uint8_t *)d_out, n);
+    else k_g1_map_fields<<<grid_for(n), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_u, (uint8_t *)d_out, n);
+    return check_launch(g2 ? "k_g2_map_fields" : "k_g1_map_fields");
+}
+static int map_fields_host(bool g2, const void *u, size_t n, void *out) {
+    if (!n) return GPBC_OK;
+    if (!u || !out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    TRY(bind_device());
+    size_t pt = g2 ? GPBC_G2_BYTES : GPBC_G1_BYTES;               // two field elements occupy as many bytes as one point
+    DevBuf dU, dO;
+    TRY(dU.upload(u, n * pt)); TRY(dO.alloc(n * pt));
+    TRY(map_fields_dev(g2, dU.p, n, dO.p, nullptr));
+    TRY(sync_default());
+    return dO.download(out, n * pt);
+}
+int gpbc_g1_map_to_curve_batch(const void *u, size_t n, void *o) { return map_fields_host(false, u, n, o); }
+int gpbc_g2_map_to_curve_batch(const void *u, size_t n, void *o) { return map_fields_host(true, u, n, o); }
+int gpbc_g1_map_to_curve_batch_dev(const void *u, size_t n, void *o, void *st) { return map_fields_dev(false, u, n, o, st); }
+int gpbc_g2_map_to_curve_batch_dev(const void *u, size_t n, void *o, void *st) { return map_fields_dev(true, u, n, o, st); }
 
 }  // extern "C"

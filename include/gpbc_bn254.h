@@ -144,6 +144,18 @@ int gpbc_g1_unmarshal_batch_dev(const void *d_in, size_t elem_bytes, size_t n, v
 int gpbc_g2_unmarshal_batch_dev(const void *d_in, size_t elem_bytes, size_t n, void *d_pts_out, uint8_t *d_ok_out, void *stream);
 int gpbc_gt_unmarshal_batch_dev(const void *d_in, size_t n, void *d_gt_out, uint8_t *d_ok_out, void *stream);
 
+/* ---- hash to curve, group part -----------------------------------------------------------------
+ * bn254.HashToG1(msg, dst) / HashToG2(msg, dst) (hash/hash_to.go:113-119,169-175,204-210,271-277) after hash_to_field:
+ *   u = fp.Hash(msg, dst, 2)  (G2: 2 E2 elements from 4 base-field elements; expand_message_xmd(SHA-256), L = 48 — byte
+ *   hashing, stays on the host: the cgo shim calls gnark's fp.Hash, the Python mirror uses hashlib)
+ *   out = MapToCurve(u[0]) + MapToCurve(u[1])            Shallue-van de Woestijne map, RFC 9380 Appendix F.1, Z = 1
+ *   G2: out = ClearCofactor(out)                         [x]P + psi([3x]P) + psi^2([x]P) + psi^3(P)
+ * u: n x 2 field elements in gnark's in-memory layout (G1: 2 x 32 B, G2: 2 x 64 B per output point); out: n points. */
+int gpbc_g1_map_to_curve_batch(const void *u, size_t n, void *out);
+int gpbc_g2_map_to_curve_batch(const void *u, size_t n, void *out);
+int gpbc_g1_map_to_curve_batch_dev(const void *d_u, size_t n, void *d_out, void *stream);
+int gpbc_g2_map_to_curve_batch_dev(const void *d_u, size_t n, void *d_out, void *stream);
+
 /* ---- field-level entry (kernel unit tests) ------------------------------------------------------ */
 int gpbc_fp_mul_batch(const void *a, const void *b, size_t n, void *out);
 

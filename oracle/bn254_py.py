@@ -219,9 +219,13 @@ def g2_mul(a, k):
     return r
 
 def g2_frobenius(q):
+    if q is None:
+        return None
     return (f2_mul(f2_conj(q[0]), GAMMA1_2), f2_mul(f2_conj(q[1]), GAMMA1_3))
 
 def g2_frobenius2(q):
+    if q is None:
+        return None
     return (f2_mul(q[0], NGAMMA_2), f2_mul(q[1], NGAMMA_3))
 
 
@@ -483,6 +487,156 @@ def gt_unmarshal(buf):
     flat = list(reversed(vals))                       # C0.B0.A0, C0.B0.A1, ..., C1.B2.A1
     cs = [(flat[2 * i], flat[2 * i + 1]) for i in range(6)]
     return ((cs[0], cs[1], cs[2]), (cs[3], cs[4], cs[5])), True
+
+
+# ----------------------------------------------------------------------------- hash to curve
+# bn254.HashToG1 / HashToG2 (reference hash/hash_to.go:113-119,169-175,204-210,271-277) [EXT, parity unpinned]:
+# RFC 9380 hash_to_curve with expand_message_xmd(SHA-256), L = 48, two field elements, the Shallue-van de Woestijne map
+# (RFC 9380 §6.6.1 / Appendix F.1 straight-line version; gnark-crypto's MapToCurve1 / MapToCurve2 are that listing), point
+# addition, and for G2 the cofactor clearing of Fuentes-Castaneda et al. §6.1:  [x]P + psi([3x]P) + psi^2([x]P) + psi^3(P).
+# Z is the first value accepted by RFC 9380 Appendix H.1 find_z_svdw (candidates 1, -1, 2, -2, ...): Z = 1 for both
+# y^2 = x^3 + 3 and the twist (computed below, not assumed).
+def expand_message_xmd(msg, dst, n):
+    """RFC 9380 §5.3.1 with SHA-256 (b = 32, s = 64)."""
+    if len(dst) > 255:
+        dst = hashlib.sha256(b"H2C-OVERSIZE-DST-" + dst).digest()
+    ell = (n + 31) // 32
+    if ell > 255 or n > 65535:
+        raise ValueError("expand_message_xmd: length too large")
+    dst_prime = dst + bytes([len(dst)])
+    b0 = hashlib.sha256(bytes(64) + msg + n.to_bytes(2, "big") + b"\x00" + dst_prime).digest()
+    bi = hashlib.sha256(b0 + b"\x01" + dst_prime).digest()
+    out = bi
+    for i in range(2, ell + 1):
+        bi = hashlib.sha256(bytes(a ^ b for a, b in zip(b0, bi)) + bytes([i]) + dst_prime).digest()
+        out += bi
+    return out[:n]
+
+H2C_L = 48
+
+def hash_to_field_fp(msg, dst, count):
+    u = expand_message_xmd(msg, dst, count * H2C_L)
+    return [int.from_bytes(u[H2C_L * i:H2C_L * (i + 1)], "big") % P for i in range(count)]
+
+def hash_to_field_fp2(msg, dst, count):
+    u = expand_message_xmd(msg, dst, 2 * count * H2C_L)
+    e = [int.from_bytes(u[H2C_L * i:H2C_L * (i + 1)], "big") % P for i in range(2 * count)]
+    return [(e[2 * i], e[2 * i + 1]) for i in range(count)]
+
+class _FpOps:
+    zero, one = 0, 1
+    b = B_G1
+    @staticmethod
+    def add(a, b): return (a + b) % P
+    @staticmethod
+    def sub(a, b): return (a - b) % P
+    @staticmethod
+    def neg(a): return (-a) % P
+    @staticmethod
+    def mul(a, b): return a * b % P
+    @staticmethod
+    def inv0(a): return pow(a, P - 2, P)
+    @staticmethod
+    def is_square(a): return pow(a, (P - 1) // 2, P) in (0, 1)
+    @staticmethod
+    def sqrt(a): return fp_sqrt(a)
+    @staticmethod
+    def sgn0(a): return a & 1
+    @staticmethod
+    def small(k): return k % P
+
+class _Fp2Ops:
+    zero, one = F2_ZERO, F2_ONE
+    b = B_G2
+    add, sub, neg, mul = staticmethod(f2_add), staticmethod(f2_sub), staticmethod(f2_neg), staticmethod(f2_mul)
+    @staticmethod
+    def inv0(a): return F2_ZERO if a == F2_ZERO else f2_inv(a)
+    @staticmethod
+    def is_square(a): return pow((a[0] * a[0] + a[1] * a[1]) % P, (P - 1) // 2, P) in (0, 1)
+    @staticmethod
+    def sqrt(a): return f2_sqrt(a)
+    @staticmethod
+    def sgn0(a): return (a[0] & 1) | ((a[0] == 0) & (a[1] & 1))       # RFC 9380 §4.1, m = 2
+    @staticmethod
+    def small(k): return (k % P, 0)
+
+def find_z_svdw(F):
+    """RFC 9380 Appendix H.1 (A = 0)."""
+    g = lambda x: F.add(F.mul(F.mul(x, x), x), F.b)
+    ctr = 1
+    while True:
+        for z in (F.small(ctr), F.small(-ctr)):
+            gz = g(z)
+            if gz == F.zero:
+                continue
+            h = F.neg(F.mul(F.mul(F.small(3), F.mul(z, z)), F.inv0(F.mul(F.small(4), gz))))
+            if h == F.zero or not F.is_square(h):
+                continue
+            if F.is_square(gz) or F.is_square(g(F.mul(F.neg(z), F.inv0(F.small(2))))):
+                return z
+        ctr += 1
+
+def svdw_constants(F):
+    z = find_z_svdw(F)
+    gz = F.add(F.mul(F.mul(z, z), z), F.b)
+    c1 = gz
+    c2 = F.mul(F.neg(z), F.inv0(F.small(2)))
+    three_z2 = F.mul(F.small(3), F.mul(z, z))
+    c3 = F.sqrt(F.mul(F.neg(gz), three_z2))
+    if F.sgn0(c3) == 1:
+        c3 = F.neg(c3)                                   # sgn0(c3) MUST equal 0
+    c4 = F.mul(F.mul(F.small(-4), gz), F.inv0(three_z2))
+    return z, c1, c2, c3, c4
+
+def map_to_curve_svdw(F, consts, u):
+    """RFC 9380 Appendix F.1, steps 1-35 (A = 0)."""
+    z, c1, c2, c3, c4 = consts
+    g = lambda x: F.add(F.mul(F.mul(x, x), x), F.b)
+    tv1 = F.mul(F.mul(u, u), c1)
+    tv2 = F.add(F.one, tv1)
+    tv1 = F.sub(F.one, tv1)
+    tv3 = F.inv0(F.mul(tv1, tv2))
+    tv4 = F.mul(F.mul(F.mul(u, tv1), tv3), c3)
+    x1 = F.sub(c2, tv4)
+    gx1 = g(x1)
+    e1 = F.is_square(gx1)
+    x2 = F.add(c2, tv4)
+    gx2 = g(x2)
+    e2 = F.is_square(gx2) and not e1
+    x3 = F.mul(F.mul(tv2, tv2), tv3)
+    x3 = F.add(F.mul(F.mul(x3, x3), c4), z)
+    x = x1 if e1 else x3
+    x = x2 if e2 else x
+    y = F.sqrt(g(x))
+    if F.sgn0(u) != F.sgn0(y):
+        y = F.neg(y)
+    return (x, y)
+
+SVDW_G1 = svdw_constants(_FpOps)
+SVDW_G2 = svdw_constants(_Fp2Ops)
+
+def g2_clear_cofactor(q):
+    """[x]Q + psi([3x]Q) + psi^2([x]Q) + psi^3(Q), x = u (the curve parameter)."""
+    xq = g2_mul_plain(q, U)
+    t1 = g2_frobenius(g2_add(g2_add(xq, xq), xq))
+    t2 = g2_frobenius(g2_frobenius(xq))
+    t3 = g2_frobenius(g2_frobenius(g2_frobenius(q)))
+    return g2_add(g2_add(g2_add(xq, t1), t2), t3)
+
+def map_fields_to_g1(u0, u1):
+    """The tail of HashToG1: both field elements through the map, then one addition (cofactor 1)."""
+    return g1_add(map_to_curve_svdw(_FpOps, SVDW_G1, u0), map_to_curve_svdw(_FpOps, SVDW_G1, u1))
+
+def map_fields_to_g2(u0, u1):
+    return g2_clear_cofactor(g2_add(map_to_curve_svdw(_Fp2Ops, SVDW_G2, u0), map_to_curve_svdw(_Fp2Ops, SVDW_G2, u1)))
+
+def hash_to_g1(msg, dst):
+    u = hash_to_field_fp(msg, dst, 2)
+    return map_fields_to_g1(u[0], u[1])
+
+def hash_to_g2(msg, dst):
+    u = hash_to_field_fp2(msg, dst, 2)
+    return map_fields_to_g2(u[0], u[1])
 
 
 # ----------------------------------------------------------------------------- deterministic synthetic inputs

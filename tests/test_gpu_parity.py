@@ -394,3 +394,62 @@ def test_wire_round_trip_large_device_path(eng):
     back, ok = eng.gt_unmarshal(eng.gt_marshal(gt))
     assert bool(ok.all()) and torch.equal(back, gt)
     assert eng.gt_marshal(gt)[5].cpu().numpy().tobytes() == bytes(383) + b"\x01"      # e(inf, Q) = 1
+
+
+# ---------------------------------------------------------------------------------------- hash to curve (§8 f-1)
+def test_hash_to_curve_golden(eng):
+    from gopairingbasedcryptography_amd import hash_to
+    g = load_golden("hash_to_curve.json")
+    dsts = {k: v.encode() for k, v in g["dsts"].items()}
+    for key, fn in (("g1", hash_to.hash_to_g1), ("g2", hash_to.hash_to_g2)):
+        for dk in sorted({c["dst"] for c in g[key]}):
+            cs = [c for c in g[key] if c["dst"] == dk]
+            out = fn([c["msg"].encode() for c in cs], dsts[dk])
+            for i, c in enumerate(cs):
+                assert out[i].tobytes().hex() == c["point"], (key, dk, c["msg"])
+    rows = cat([o.fp_to_mont_bytes(int(c["u"][0])).hex() + o.fp_to_mont_bytes(int(c["u"][1])).hex() for c in g["g1_fields"]])
+    out = eng.map_to_g1(rows)
+    for i, c in enumerate(g["g1_fields"]):
+        assert out[i].tobytes().hex() == c["point"], ("g1_fields", i)
+    f2 = lambda v: o.f2_to_bytes((int(v[0]), int(v[1]))).hex()
+    out = eng.map_to_g2(cat([f2(c["u"][0]) + f2(c["u"][1]) for c in g["g2_fields"]]))
+    for i, c in enumerate(g["g2_fields"]):
+        assert out[i].tobytes().hex() == c["point"], ("g2_fields", i)
+    # the reference's four entry points
+    assert hash_to.ToG1("user@example.com").tobytes().hex() == [c for c in g["g1"] if c["msg"] == "user@example.com" and c["dst"] == "string_g1"][0]["point"]
+    assert hash_to.BytesToG1(b"abc").tobytes().hex() == [c for c in g["g1"] if c["msg"] == "abc" and c["dst"] == "bytes_g1"][0]["point"]
+    assert hash_to.ToG2("abc").tobytes().hex() == [c for c in g["g2"] if c["msg"] == "abc" and c["dst"] == "string_g2"][0]["point"]
+
+
+def test_hash_to_curve_large_batch_properties(eng):
+    """Size-independent properties at 2^13 messages: every point passes the curve / subgroup checks of the independent
+    unmarshal kernels, the map is deterministic, and BLS sign / verify closes over hashed message points:
+    e(pk, H(m)) == e(g1, [sk]H(m))  (signature/bls01_signature/bls_signature.go:58-89 with the real hash)."""
+    from gopairingbasedcryptography_amd import hash_to
+    n = 1 << 13
+    msgs = [b"message %d" % i for i in range(n)]
+    H1 = hash_to.hash_to_g1(msgs, hash_to.DST_BYTES_G1)
+    H2 = hash_to.hash_to_g2(msgs, hash_to.DST_BYTES_G2)
+    for pts, marshal, unmarshal in ((H1, eng.g1_marshal, eng.g1_unmarshal), (H2, eng.g2_marshal, eng.g2_unmarshal)):
+        back, ok = unmarshal(marshal(pts))
+        assert ok.all() and (back == pts).all()
+        assert len({r.tobytes() for r in pts}) == n and pts.any(axis=1).all()        # distinct, none at infinity
+    assert (hash_to.hash_to_g2(msgs[:64], hash_to.DST_BYTES_G2) == H2[:64]).all()
+    m = 256
+    g1, g2 = eng.generators()
+    sk = scalars("bls-sk", m)
+    pk = eng.g1_scalar_mul(g1, sk)
+    sig = eng.g2_scalar_mul(H2[:m], sk)
+    lhs = eng.pair_batch(pk, H2[:m])
+    rhs = eng.pair_batch(np.tile(g1, m), sig)
+    assert (lhs == rhs).all()
+    neg_sig = sig.copy().reshape(m, 128)
+    P = np.stack([pk.reshape(m, 64), np.tile(g1, (m, 1))], axis=1).reshape(-1)
+    # PairingCheck([pk, g1], [H(m), -sigma]) per message; a wrong message must fail
+    from gopairingbasedcryptography_amd.sharding import shard_range  # noqa: F401  (import check only)
+    negY = eng.g2_scalar_mul(sig, [o.R - 1] * m)
+    Qv = np.stack([H2[:m], negY.reshape(m, 128)], axis=1).reshape(-1)
+    ok = eng.pairing_check_batch(P, Qv, np.arange(0, 2 * m + 1, 2))
+    assert ok.all()
+    Qbad = np.stack([np.roll(H2[:m], 1, axis=0), negY.reshape(m, 128)], axis=1).reshape(-1)
+    assert not eng.pairing_check_batch(P, Qbad, np.arange(0, 2 * m + 1, 2)).any()

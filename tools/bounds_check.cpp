@@ -12,6 +12,7 @@
 #include "../gopairingbasedcryptography_amd/csrc/pairing29.cuh"
 #include "../gopairingbasedcryptography_amd/csrc/pairing29_pair.cuh"
 #include "../gopairingbasedcryptography_amd/csrc/wire29.cuh"
+#include "../gopairingbasedcryptography_amd/csrc/h2c29.cuh"
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -190,6 +191,20 @@ void hc_wire_decode(int kind, const uint8_t *in, int elem_bytes, size_t n, uint8
         if (kind == 0) ok[i] = g1_wire_decode(out + 64 * i, in + (size_t)elem_bytes * i, elem_bytes);
         else if (kind == 1) ok[i] = g2_wire_decode(out + 128 * i, in + (size_t)elem_bytes * i, elem_bytes);
         else ok[i] = gt_wire_decode(out + 384 * i, in + 384 * i);
+    }
+}
+// hash to curve, group part (csrc/h2c29.cuh): U = n x 2 field elements (gnark fp.Element / E2), out = n affine points
+void hc_map_fields(int g2, const uint8_t *U, size_t n, uint8_t *out) {
+    for (size_t i = 0; i < n; i++) {
+        if (!g2) {
+            AffP<Fe> r;
+            g1_map_fields(r, fe_load(U + 64 * i), fe_load(U + 64 * i + 32));
+            fe_store(out + 64 * i, r.x); fe_store(out + 64 * i + 32, r.y);
+        } else {
+            AffP<F2> r;
+            g2_map_fields(r, f2_load(U + 128 * i), f2_load(U + 128 * i + 64));
+            f2_store(out + 128 * i, r.x); f2_store(out + 128 * i + 64, r.y);
+        }
     }
 }
 // worst-case figures since process start: [max |int64 column|, max limb bound, max value bound (units of p),

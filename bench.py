@@ -225,6 +225,10 @@ def main():
         wire["gt_marshal_per_s"] = rate(bn254.gt_marshal, gw) * nw / B
         wire["gt_unmarshal_per_s"] = rate(bn254.gt_unmarshal, bn254.gt_marshal(gw)) * nw / B
         sec["wire"] = wire
+        # hash to curve, group part (§8 f-1): two field elements per point, taken from the scalar stream
+        uf = torch.from_numpy(bench_scalars("h2c", rank * nw * 4, nw * 4).copy()).to(dev).reshape(-1, 32)   # values < r < p: valid fp.Elements
+        sec["g1_map_to_curve_per_s"] = rate(bn254.map_to_g1, uf[:2 * nw].reshape(nw, 64).contiguous()) * nw / B
+        sec["g2_map_to_curve_per_s"] = rate(bn254.map_to_g2, uf.reshape(nw, 128).contiguous()) * nw / B
         ne = min(B, 1 << 16)                              # GT.Exp by full-size exponents
         sec["gt_exp_per_s"] = rate(bn254.gt_exp, gt[:ne].contiguous(), ks[:ne].contiguous()) * ne / B
         result["secondary"] = sec

@@ -78,6 +78,30 @@ template <class F> GPBC_INLINE void jac_add_mixed(JacP<F> &r, const JacP<F> &p, 
     F z3 = g_norm(g_sub(g_sub(g_sqr(g_norm(g_add(p.z, H))), Z1Z1), HH));
     r.x = x3; r.y = y3; r.z = z3; r.inf = false;
 }
+// add-2007-bl with the exceptional cases; in/out N-class
+template <class F> GPBC_INLINE void jac_add(JacP<F> &r, const JacP<F> &p, const JacP<F> &q) {
+    if (q.inf) { r = p; return; }
+    if (p.inf) { r = q; return; }
+    F Z1Z1 = g_sqr(p.z), Z2Z2 = g_sqr(q.z);
+    F U1 = g_mul(p.x, Z2Z2), U2 = g_mul(q.x, Z1Z1);
+    F S1 = g_mul(g_mul(p.y, q.z), Z2Z2), S2 = g_mul(g_mul(q.y, p.z), Z1Z1);
+    F H = g_norm(g_sub(U2, U1));
+    F rr = g_norm(g_sub(S2, S1));
+    if (g_is_zero(H)) {
+        if (g_is_zero(rr)) { jac_dbl(r, p); return; }
+        jac_set_inf(r);
+        return;
+    }
+    rr = g_norm(g_dbl(rr));
+    F HH = g_sqr(H);
+    F I = g_norm(g_dbl(g_dbl(HH)));
+    F J = g_mul(H, I);
+    F V = g_mul(U1, I);
+    F x3 = g_norm(g_sub(g_sub(g_sqr(rr), J), g_dbl(V)));
+    F y3 = g_norm(g_sub(g_mul(rr, g_norm(g_sub(V, x3))), g_dbl(g_mul(S1, J))));
+    F z3 = g_mul(g_norm(g_sub(g_sub(g_sqr(g_norm(g_add(p.z, q.z))), Z1Z1), Z2Z2)), H);
+    r.x = x3; r.y = y3; r.z = z3; r.inf = false;
+}
 template <class F> GPBC_INLINE void jac_to_affine(AffP<F> &r, const JacP<F> &p) {
     if (p.inf) { g_set_zero(r.x); g_set_zero(r.y); r.inf = true; return; }
     F zi = g_inv(p.z);
@@ -175,38 +199,80 @@ template <> GPBC_INLINE Fe g_sel<Fe>(bool c, const Fe &a, const Fe &b) {
 }
 template <> GPBC_INLINE F2 g_sel<F2>(bool c, const F2 &a, const F2 &b) { return F2{g_sel<Fe>(c, a.a0, b.a0), g_sel<Fe>(c, a.a1, b.a1)}; }
 
-// [k]base for any 256-bit k (Jacobian result).  GLV split k = k1 + k2*lambda, then ONE joint double-and-add over the
-// ~128-bit halves with the table {P1, P2, P1+P2} (P1 = +-P, P2 = +-phi(P)): every step is a doubling plus at most one
-// mixed addition.  In a 64-lane wave a per-lane `if (bit) add` costs the addition whenever ANY lane has the bit set, i.e.
-// practically always; two separate conditional additions per step therefore cost two additions per step for the wave,
-// the joint table costs one.
-// P1+P2 is kept "affine" without an inversion: with H = x2 - x1 the three table points share the Jacobian Z = H,
-//   P1 = (x1 H^2, y1 H^3, H),  P2 = (x2 H^2, y2 H^3, H),  P1+P2 = (R^2 - H^3 - 2 x1 H^2, R (x1 H^2 - X3) - y1 H^3, H),  R = y2 - y1,
-// i.e. they are affine points of the isomorphic curve y^2 = x^3 + b H^6; the a = 0 doubling and the mixed addition do not
-// involve b, so the whole loop runs there and the result (X, Y, Z') maps back as (X, Y, Z' H).
+// [k]base for any 256-bit k (Jacobian result).  GLV split k = k1 + k2*lambda, then ONE joint loop over the ~130-bit halves
+// in FIXED 2-bit windows: two doublings and one mixed addition of T[d1][d2] = d1*P1 + d2*P2 (P1 = +-P, P2 = +-phi(P)) per
+// step.  Why fixed windows: in a 64-lane wave a per-lane `if (digit) add` costs the addition whenever ANY lane has a
+// non-zero digit, i.e. practically always, so sparse recodings (NAF, JSF) buy nothing; what counts is the number of
+// addition SLOTS, and aligned 2-bit windows halve them (65 instead of 130).
+// The 15 table points are built in Jacobian coordinates (2 doublings, 8 mixed and 1 general addition; 2P2 and 3P2 are
+// phi(2P1), phi(3P1) with the sign s1*s2) and then brought to ONE common Z = W = product of their 11 distinct Z's without
+// any inversion:  (X, Y, Z) ~ (X l^2, Y l^3, W),  l = W / Z  from prefix / suffix products.  Points sharing a Z are affine
+// points of the isomorphic curve y^2 = x^3 + b W^6; the a = 0 doubling and the mixed addition never touch b, so the
+// whole loop runs there and the result (X, Y, Z') maps back as (X, Y, Z' W).
+template <class F> GPBC_INLINE JacP<F> jac_phi(const JacP<F> &p, bool flip) {
+    return JacP<F>{glv_phi_x(p.x), flip ? g_neg(p.y) : p.y, p.z, p.inf};
+}
+template <class F> GPBC_NOINLINE void glv_table29(AffP<F> (&tab)[16], F &W, const AffP<F> &p1, const AffP<F> &p2, bool flip) {
+    F one;
+    g_set_one(one);
+    // J: 0 D1=2P1, 1 T1=3P1, 2 (1,1), 3 (2,2), 4 (3,3), 5 (1,2), 6 (2,1), 7 (1,3), 8 (3,1), 9 (2,3), 10 (3,2)
+    JacP<F> J[11];
+    JacP<F> p1j{p1.x, p1.y, one, false};
+    jac_dbl(J[0], p1j);
+    jac_add_mixed(J[1], J[0], p1);
+    jac_add_mixed(J[2], p1j, p2);
+    jac_dbl(J[3], J[2]);
+    jac_add(J[4], J[3], J[2]);
+    JacP<F> d2 = jac_phi(J[0], flip), t2 = jac_phi(J[1], flip);        // 2P2, 3P2 (same Z as 2P1, 3P1)
+    jac_add_mixed(J[5], d2, p1);
+    jac_add_mixed(J[6], J[0], p2);
+    jac_add_mixed(J[7], t2, p1);
+    jac_add_mixed(J[8], J[1], p2);
+    jac_add_mixed(J[9], J[7], p1);
+    jac_add_mixed(J[10], J[8], p2);
+    // l[i] = product of all Z's except J[i].z
+    F pre[11], l[11];
+    F run = one;
+    for (int i = 0; i < 11; i++) { pre[i] = run; run = g_mul(run, J[i].z); }
+    W = run;
+    run = one;
+    for (int i = 10; i >= 0; i--) { l[i] = g_mul(pre[i], run); run = g_mul(run, J[i].z); }
+    // index = 4 * d1 + d2
+    static constexpr int IDX[11] = {8, 12, 5, 10, 15, 6, 9, 7, 13, 11, 14};
+    F l2d = one, l3d = one, l2t = one, l3t = one;
+    for (int i = 0; i < 11; i++) {
+        F l2 = g_sqr(l[i]), l3 = g_mul(l2, l[i]);
+        tab[IDX[i]] = AffP<F>{g_mul(J[i].x, l2), g_mul(J[i].y, l3), false};
+        if (i == 0) { l2d = l2; l3d = l3; }
+        if (i == 1) { l2t = l2; l3t = l3; }
+    }
+    tab[2] = AffP<F>{g_mul(d2.x, l2d), g_mul(d2.y, l3d), false};
+    tab[3] = AffP<F>{g_mul(t2.x, l2t), g_mul(t2.y, l3t), false};
+    F w2 = g_sqr(W), w3 = g_mul(w2, W);
+    tab[4] = AffP<F>{g_mul(p1.x, w2), g_mul(p1.y, w3), false};
+    tab[1] = AffP<F>{g_mul(p2.x, w2), g_mul(p2.y, w3), false};
+    tab[0] = tab[1];                                                  // never added (digit pair 0,0)
+}
 template <class F> GPBC_INLINE void scalar_mul29_jac(JacP<F> &acc, const AffP<F> &base, const uint32_t k[8]) {
     GlvSplit s;
     glv_split(s, k);
-    F y1 = s.neg1 ? g_neg(base.y) : base.y, y2 = s.neg2 ? g_neg(base.y) : base.y;
-    F x2 = glv_phi_x(base.x);
-    F H = g_norm(g_sub(x2, base.x)), R = g_norm(g_sub(y2, y1));
-    F HH = g_sqr(H), HHH = g_mul(H, HH);
-    AffP<F> p1{g_mul(base.x, HH), g_mul(y1, HHH), base.inf};
-    AffP<F> p2{g_mul(x2, HH), g_mul(y2, HHH), base.inf};
-    F X3 = g_norm(g_sub(g_sub(g_sqr(R), HHH), g_dbl(p1.x)));
-    AffP<F> p3{X3, g_norm(g_sub(g_mul(R, g_norm(g_sub(p1.x, X3))), p1.y)), base.inf};
     jac_set_inf(acc);
     int top = 159;
     while (top >= 0 && !(((s.k1[top >> 5] | s.k2[top >> 5]) >> (top & 31)) & 1)) top--;
-    for (int i = top; i >= 0; i--) {
+    if (base.inf || top < 0) return;
+    AffP<F> p1{base.x, s.neg1 ? g_neg(base.y) : base.y, false};
+    AffP<F> p2{glv_phi_x(base.x), s.neg2 ? g_neg(base.y) : base.y, false};
+    AffP<F> tab[16];
+    F W;
+    glv_table29<F>(tab, W, p1, p2, s.neg1 != s.neg2);
+    for (int i = top >> 1; i >= 0; i--) {
         jac_dbl(acc, acc);
-        const bool b1 = (s.k1[i >> 5] >> (i & 31)) & 1, b2 = (s.k2[i >> 5] >> (i & 31)) & 1;
-        if (b1 || b2) {
-            AffP<F> t{g_sel<F>(b1 && b2, p3.x, g_sel<F>(b1, p1.x, p2.x)), g_sel<F>(b1 && b2, p3.y, g_sel<F>(b1, p1.y, p2.y)), base.inf};
-            jac_add_mixed(acc, acc, t);
-        }
+        jac_dbl(acc, acc);
+        const int b = 2 * i;
+        const int idx = 4 * (int)((s.k1[b >> 5] >> (b & 31)) & 3) + (int)((s.k2[b >> 5] >> (b & 31)) & 3);
+        if (idx) jac_add_mixed(acc, acc, tab[idx]);
     }
-    if (!acc.inf) acc.z = g_mul(acc.z, H);               // back from the curve scaled by H
+    if (!acc.inf) acc.z = g_mul(acc.z, W);               // back from the curve scaled by W
 }
 template <class F> GPBC_INLINE void scalar_mul29(AffP<F> &out, const AffP<F> &base, const uint32_t k[8]) {
     JacP<F> acc;

@@ -74,30 +74,6 @@ template <class F> GPBC_NOINLINE void map_to_curve_svdw(AffP<F> &out, const F &u
     out.x = x; out.y = y; out.inf = false;
 }
 
-// add-2007-bl with the exceptional cases; in/out N-class
-template <class F> GPBC_INLINE void jac_add(JacP<F> &r, const JacP<F> &p, const JacP<F> &q) {
-    if (q.inf) { r = p; return; }
-    if (p.inf) { r = q; return; }
-    F Z1Z1 = g_sqr(p.z), Z2Z2 = g_sqr(q.z);
-    F U1 = g_mul(p.x, Z2Z2), U2 = g_mul(q.x, Z1Z1);
-    F S1 = g_mul(g_mul(p.y, q.z), Z2Z2), S2 = g_mul(g_mul(q.y, p.z), Z1Z1);
-    F H = g_norm(g_sub(U2, U1));
-    F rr = g_norm(g_sub(S2, S1));
-    if (g_is_zero(H)) {
-        if (g_is_zero(rr)) { jac_dbl(r, p); return; }
-        jac_set_inf(r);
-        return;
-    }
-    rr = g_norm(g_dbl(rr));
-    F HH = g_sqr(H);
-    F I = g_norm(g_dbl(g_dbl(HH)));
-    F J = g_mul(H, I);
-    F V = g_mul(U1, I);
-    F x3 = g_norm(g_sub(g_sub(g_sqr(rr), J), g_dbl(V)));
-    F y3 = g_norm(g_sub(g_mul(rr, g_norm(g_sub(V, x3))), g_dbl(g_mul(S1, J))));
-    F z3 = g_mul(g_norm(g_sub(g_sub(g_sqr(g_norm(g_add(p.z, q.z))), Z1Z1), Z2Z2)), H);
-    r.x = x3; r.y = y3; r.z = z3; r.inf = false;
-}
 // psi^j on Jacobian coordinates of the twist: (conj^j X * gamma_j,2, conj^j Y * gamma_j,3, conj^j Z)
 GPBC_INLINE JacP<F2> jac_psi(const JacP<F2> &p, int j) {
     if (p.inf) return p;

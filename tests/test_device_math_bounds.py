@@ -150,3 +150,16 @@ def test_gt_exp_pair_under_bounds(hc):
     out = np.zeros(len(A) * 384, dtype=np.uint8)
     hc.hc_gt_exp_pair(vp(a), vp(k), ctypes.c_size_t(len(A)), vp(out))
     assert out.tobytes() == b"".join(exp)
+
+
+def test_safegcd_inversion_matches_fermat_and_oracle(hc):
+    """fe_inv (Bernstein-Yang divsteps, 600 constant-time steps on 30-bit limbs) against the Fermat power of the same
+    header and against Python's pow: edge values (0 -> 0, 1, p-1, powers of two) and 2000 random elements."""
+    import random
+    random.seed(7)
+    vals = [0, 1, 2, o.P - 1, o.P - 2, (o.P - 1) // 2, 3, 1 << 253] + [1 << k for k in range(0, 254, 7)] + [random.randrange(o.P) for _ in range(2000)]
+    a = np.frombuffer(b"".join(o.fp_to_mont_bytes(v) for v in vals), dtype=np.uint8).copy()
+    o1, o2 = np.zeros(len(vals) * 32, dtype=np.uint8), np.zeros(len(vals) * 32, dtype=np.uint8)
+    hc.hc_fp_inv(vp(a), ctypes.c_size_t(len(vals)), vp(o1), vp(o2))
+    exp = b"".join(o.fp_to_mont_bytes(pow(v, o.P - 2, o.P)) for v in vals)
+    assert o1.tobytes() == exp and o2.tobytes() == exp

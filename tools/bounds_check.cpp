@@ -111,6 +111,14 @@ void hc_fp_mul(const uint8_t *A, const uint8_t *B, size_t n, uint8_t *out) {
     // gnark-form a (= x R) and b (= y R), R = 2^256: internal product of the converted operands is x y R' -> stored as x y R
     for (size_t i = 0; i < n; i++) fe_store(out + 32 * i, fe_mul(fe_load(A + 32 * i), fe_load(B + 32 * i)));
 }
+// out = a^-1 by the safegcd inversion, out2 = by the Fermat power (gnark-form in and out: (xR)^-1 stored as x^-1 R)
+void hc_fp_inv(const uint8_t *A, size_t n, uint8_t *out, uint8_t *out2) {
+    for (size_t i = 0; i < n; i++) {
+        Fe a = fe_load(A + 32 * i);
+        fe_store(out + 32 * i, fe_inv(a));
+        fe_store(out2 + 32 * i, fe_inv_fermat(a));
+    }
+}
 void hc_gt_mul(const uint8_t *A, const uint8_t *B, size_t n, uint8_t *out) {
     for (size_t i = 0; i < n; i++) { F12 a, b; f12_load(a, A + 384 * i); f12_load(b, B + 384 * i); f12_store(out + 384 * i, f12_mul(a, b)); }
 }

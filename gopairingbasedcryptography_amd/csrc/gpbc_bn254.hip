@@ -144,7 +144,7 @@ __device__ __forceinline__ void g2_store_aff(uint8_t *p, const AffP<F2> &r) { f2
 #define GPBC_SMUL_K 1
 #endif
 constexpr int SMUL_K = GPBC_SMUL_K;
-GPBC_KERNEL_G1 k_g1_scalar_mul(const uint8_t *__restrict__ bases, int shared_base, const uint8_t *__restrict__ scalars, uint8_t *__restrict__ out, size_t n) {
+GPBC_KERNEL_G1 k_g1_scalar_mul(const uint8_t *__restrict__ bases, int shared_base, const uint8_t *__restrict__ scalars, uint8_t *__restrict__ out, size_t n, int32_t *__restrict__ tabws) {
     size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     size_t T = (n + SMUL_K - 1) / SMUL_K;
     if (t >= T) return;
@@ -155,7 +155,7 @@ GPBC_KERNEL_G1 k_g1_scalar_mul(const uint8_t *__restrict__ bases, int shared_bas
         AffP<Fe> b = g1_load_aff(bases + (shared_base ? 0 : i * GPBC_G1_BYTES));
         uint32_t k[8];
         load_scalar(k, scalars + i * GPBC_SCALAR_BYTES);
-        scalar_mul29_jac<Fe>(res[j], b, k);
+        scalar_mul29_jac<Fe>(res[j], b, k, tabws + t * (size_t)glv_table_dwords<Fe>());
     }
     AffP<Fe> aff[SMUL_K];
     jac_to_affine_batch<Fe, SMUL_K>(aff, res);
@@ -164,7 +164,7 @@ GPBC_KERNEL_G1 k_g1_scalar_mul(const uint8_t *__restrict__ bases, int shared_bas
         if (i < n) g1_store_aff(out + i * GPBC_G1_BYTES, aff[j]);
     }
 }
-GPBC_KERNEL k_g2_scalar_mul(const uint8_t *__restrict__ bases, int shared_base, const uint8_t *__restrict__ scalars, uint8_t *__restrict__ out, size_t n) {
+GPBC_KERNEL k_g2_scalar_mul(const uint8_t *__restrict__ bases, int shared_base, const uint8_t *__restrict__ scalars, uint8_t *__restrict__ out, size_t n, int32_t *__restrict__ tabws) {
     size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     size_t T = (n + SMUL_K - 1) / SMUL_K;
     if (t >= T) return;
@@ -175,7 +175,7 @@ GPBC_KERNEL k_g2_scalar_mul(const uint8_t *__restrict__ bases, int shared_base, 
         AffP<F2> b = g2_load_aff(bases + (shared_base ? 0 : i * GPBC_G2_BYTES));
         uint32_t k[8];
         load_scalar(k, scalars + i * GPBC_SCALAR_BYTES);
-        scalar_mul29_jac<F2>(res[j], b, k);
+        scalar_mul29_jac<F2>(res[j], b, k, tabws + t * (size_t)glv_table_dwords<F2>());
     }
     AffP<F2> aff[SMUL_K];
     jac_to_affine_batch<F2, SMUL_K>(aff, res);
@@ -369,34 +369,42 @@ int gpbc_shutdown(void) {
 }
 
 // ----------------------------------------------------------------------------------------------- device-pointer API
-// Lines workspace: 88 x 54 int32 per pairing.  One grow-only buffer per (device, stream) — calls on one stream are
-// ordered, calls on different streams get different buffers — processed in chunks so the footprint stays bounded.
+// Internal workspace: the Miller lines (88 x 54 int32 per pairing) and the per-point GLV tables of the scalar
+// multiplications (2 KB / 4 KB per point).  One grow-only buffer per (device, stream) — calls on one stream are ordered and
+// may share it, calls on different streams get different buffers — and batches are processed in chunks so the footprint
+// stays bounded.
 constexpr size_t MILLER_CHUNK = 262144;                               // pairings per chunk: 4.98 GB of lines
+constexpr size_t SMUL_CHUNK = 262144;                                 // points per chunk: 0.5 GB (G1) / 1 GB (G2) of tables
 constexpr size_t LINE_BYTES_PER_PAIR = (size_t)MILLER_LINES * LINE_WORDS * sizeof(int32_t);
-struct LinesWs { int device; hipStream_t stream; void *ptr; size_t pairs; };
+struct StreamWs { int device; hipStream_t stream; void *ptr; size_t bytes; };
 static std::mutex g_ws_mu;
-static std::vector<LinesWs> g_ws;
-static int lines_workspace(hipStream_t stream, size_t pairs, int32_t **out) {
+// Held while a call enqueues the kernels that share the stream's workspace (lines then accumulate; table build and loop
+// in one kernel): two host threads launching on the same stream must not interleave such sequences.  Enqueueing is
+// asynchronous, so the lock is held for microseconds.
+static std::mutex g_ws_seq_mu;
+static std::vector<StreamWs> g_ws;
+static int stream_workspace(hipStream_t stream, size_t bytes, int32_t **out) {
     int dev = g_device.load();
     std::lock_guard<std::mutex> lk(g_ws_mu);
     for (auto &w : g_ws)
         if (w.device == dev && w.stream == stream) {
-            if (w.pairs < pairs) {
+            if (w.bytes < bytes) {
                 HIP_TRY(hipStreamSynchronize(stream));
                 HIP_TRY(hipFree(w.ptr));
-                w.ptr = nullptr; w.pairs = 0;
-                HIP_TRY(hipMalloc(&w.ptr, pairs * LINE_BYTES_PER_PAIR));
-                w.pairs = pairs;
+                w.ptr = nullptr; w.bytes = 0;
+                HIP_TRY(hipMalloc(&w.ptr, bytes));
+                w.bytes = bytes;
             }
             *out = (int32_t *)w.ptr;
             return GPBC_OK;
         }
     void *ptr = nullptr;
-    HIP_TRY(hipMalloc(&ptr, pairs * LINE_BYTES_PER_PAIR));
-    g_ws.push_back(LinesWs{dev, stream, ptr, pairs});
+    HIP_TRY(hipMalloc(&ptr, bytes));
+    g_ws.push_back(StreamWs{dev, stream, ptr, bytes});
     *out = (int32_t *)ptr;
     return GPBC_OK;
 }
+static int lines_workspace(hipStream_t stream, size_t pairs, int32_t **out) { return stream_workspace(stream, pairs * LINE_BYTES_PER_PAIR, out); }
 static void free_workspaces() {
     std::lock_guard<std::mutex> lk(g_ws_mu);
     for (auto &w : g_ws) if (w.ptr) { (void)hipSetDevice(w.device); (void)hipFree(w.ptr); }
@@ -409,6 +417,7 @@ int gpbc_miller_loop_dev(const void *dP, const void *dQ, size_t n, void *d_f_out
     TRY(bind_device());
     hipStream_t st = (hipStream_t)stream;
     size_t chunk = n < MILLER_CHUNK ? n : MILLER_CHUNK;
+    std::lock_guard<std::mutex> seq(g_ws_seq_mu);
     int32_t *lines = nullptr;
     TRY(lines_workspace(st, chunk, &lines));
     for (size_t off = 0; off < n; off += chunk) {
@@ -449,11 +458,24 @@ static int scalar_mul_dev(bool g2, const void *d_bases, size_t nbase, const void
     if (!d_bases || !d_scalars || !d_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
     if (nbase != 1 && nbase != n) return fail(GPBC_ERR_INVALID_ARG, "nbase must be 1 or n");
     TRY(bind_device());
-    int shared = (nbase == 1 && n != 1) ? 1 : 0;
-    size_t lanes = (n + SMUL_K - 1) / SMUL_K;
-    if (g2) k_g2_scalar_mul<<<grid_for(lanes), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_bases, shared, (const uint8_t *)d_scalars, (uint8_t *)d_out, n);
-    else k_g1_scalar_mul<<<grid_for(lanes), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_bases, shared, (const uint8_t *)d_scalars, (uint8_t *)d_out, n);
-    return check_launch(g2 ? "k_g2_scalar_mul" : "k_g1_scalar_mul");
+    static_assert(SMUL_K == 1, "the table workspace is laid out for one point per lane");
+    const int shared = (nbase == 1 && n != 1) ? 1 : 0;
+    const size_t pt = g2 ? GPBC_G2_BYTES : GPBC_G1_BYTES;
+    const size_t tab_bytes = sizeof(int32_t) * (g2 ? (size_t)glv_table_dwords<F2>() : (size_t)glv_table_dwords<Fe>());
+    hipStream_t st = (hipStream_t)stream;
+    const size_t chunk = n < SMUL_CHUNK ? n : SMUL_CHUNK;
+    std::lock_guard<std::mutex> seq(g_ws_seq_mu);
+    int32_t *tabws = nullptr;
+    TRY(stream_workspace(st, chunk * tab_bytes, &tabws));
+    for (size_t off = 0; off < n; off += chunk) {
+        const size_t m = n - off < chunk ? n - off : chunk;
+        const uint8_t *b = (const uint8_t *)d_bases + (shared ? 0 : off * pt), *k = (const uint8_t *)d_scalars + off * GPBC_SCALAR_BYTES;
+        uint8_t *o = (uint8_t *)d_out + off * pt;
+        if (g2) k_g2_scalar_mul<<<grid_for(m), BLOCK, 0, st>>>(b, shared, k, o, m, tabws);
+        else k_g1_scalar_mul<<<grid_for(m), BLOCK, 0, st>>>(b, shared, k, o, m, tabws);
+        TRY(check_launch(g2 ? "k_g2_scalar_mul" : "k_g1_scalar_mul"));
+    }
+    return GPBC_OK;
 }
 int gpbc_g1_scalar_mul_batch_dev(const void *b, size_t nb, const void *s, size_t n, void *o, void *st) { return scalar_mul_dev(false, b, nb, s, n, o, st); }
 int gpbc_g2_scalar_mul_batch_dev(const void *b, size_t nb, const void *s, size_t n, void *o, void *st) { return scalar_mul_dev(true, b, nb, s, n, o, st); }

@@ -55,7 +55,8 @@ template <class F, class LoadA, class StoreA> static void smul_batch(const uint8
             size_t i = t + (size_t)j * T;
             if (i >= n) { jac_set_inf(res[j]); continue; }
             uint32_t k[8]; memcpy(k, K + 32 * i, 32);
-            scalar_mul29_jac<F>(res[j], ld(B + pt * i), k);
+            alignas(16) int32_t tab[glv_table_dwords<F>()];
+            scalar_mul29_jac<F>(res[j], ld(B + pt * i), k, tab);
         }
         AffP<F> aff[KK];
         jac_to_affine_batch<F, KK>(aff, res);

@@ -229,6 +229,14 @@ def main():
         uf = torch.from_numpy(bench_scalars("h2c", rank * nw * 4, nw * 4).copy()).to(dev).reshape(-1, 32)   # values < r < p: valid fp.Elements
         sec["g1_map_to_curve_per_s"] = rate(bn254.map_to_g1, uf[:2 * nw].reshape(nw, 64).contiguous()) * nw / B
         sec["g2_map_to_curve_per_s"] = rate(bn254.map_to_g2, uf.reshape(nw, 128).contiguous()) * nw / B
+        # fixed-base window tables: generator multiplications (ScalarMultiplicationBase) and 256-term commitments (AFP25 shape)
+        fb = bn254.FixedBase(g1d)
+        sec["g1_fixed_base_mults_per_s"] = rate(fb.mul, ks)
+        fb.close()
+        nsrs, nmsm = 256, min(B // 256, 1024)
+        fbs = bn254.FixedBase(P[:nsrs].contiguous())
+        sec["g1_msm256_terms_per_s"] = rate(fbs.msm, ks[:nsrs * nmsm].contiguous()) * (nsrs * nmsm) / B
+        fbs.close()
         ne = min(B, 1 << 16)                              # GT.Exp by full-size exponents
         sec["gt_exp_per_s"] = rate(bn254.gt_exp, gt[:ne].contiguous(), ks[:ne].contiguous()) * ne / B
         result["secondary"] = sec

@@ -24,6 +24,8 @@ EXPORTS = [
     "gpbc_g1_unmarshal_batch_dev", "gpbc_g2_unmarshal_batch_dev", "gpbc_gt_unmarshal_batch_dev",
     "gpbc_g1_map_to_curve_batch", "gpbc_g2_map_to_curve_batch",
     "gpbc_g1_map_to_curve_batch_dev", "gpbc_g2_map_to_curve_batch_dev",
+    "gpbc_fixed_base_table_bytes", "gpbc_g1_fixed_base_create", "gpbc_g2_fixed_base_create", "gpbc_fixed_base_create_dev",
+    "gpbc_fixed_base_msm", "gpbc_fixed_base_msm_workspace_bytes", "gpbc_fixed_base_msm_dev", "gpbc_fixed_base_destroy",
 ]
 
 _lib = None
@@ -53,6 +55,10 @@ def load():
         lib.gpbc_multi_pair_workspace_bytes.argtypes = [ctypes.c_size_t, ctypes.c_size_t]
         lib.gpbc_sum_workspace_bytes.restype = ctypes.c_size_t
         lib.gpbc_sum_workspace_bytes.argtypes = [ctypes.c_size_t, ctypes.c_int]
+        lib.gpbc_fixed_base_table_bytes.restype = ctypes.c_size_t
+        lib.gpbc_fixed_base_table_bytes.argtypes = [ctypes.c_size_t, ctypes.c_int]
+        lib.gpbc_fixed_base_msm_workspace_bytes.restype = ctypes.c_size_t
+        lib.gpbc_fixed_base_msm_workspace_bytes.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
         _lib = lib
     return _lib
 

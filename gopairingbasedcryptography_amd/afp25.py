@@ -57,13 +57,30 @@ def digest(engine, g1, tau_powers, identities):
     return commit_g1(engine, g1, tau_powers, f), f
 
 
-def decrypt_batch(engine, g1, tau_powers, D, f_coeffs, sk, items):
+def srs_table(engine, g1, tau_powers):
+    """Fixed-base window tables (engine.FixedBase, HBM-resident) over the commitment bases (g1, [tau]_1, ..., [tau^B]_1):
+    built once per SRS, after which every commitment is ONE row of a multi-scalar multiplication."""
+    return engine.FixedBase(np.concatenate([np.asarray(g1, dtype=np.uint8).reshape(1, 64), np.asarray(tau_powers, dtype=np.uint8).reshape(-1, 64)]))
+
+
+def commit_g1_many(table, coeff_rows):
+    """[p_i(tau)]_1 for every coefficient row (lowest degree first; rows are zero-padded to the table's nbase)."""
+    rows = [[int(c) for c in r] + [0] * (table.nbase - len(r)) for r in coeff_rows]
+    return np.asarray(table.msm(rows))
+
+
+def decrypt_batch(engine, g1, tau_powers, D, f_coeffs, sk, items, table=None):
     """items: list of (identity, C1 [3,128], C2 [384]) all encrypted under the batch digest D and key sk.
-    Returns the messages [n,384]: m_i = C2_i / (e(D, C1_i[0]) e(pi_i, C1_i[1]) e(sk, C1_i[2]))."""
+    Returns the messages [n,384]: m_i = C2_i / (e(D, C1_i[0]) e(pi_i, C1_i[1]) e(sk, C1_i[2])).
+    With `table` (srs_table) all opening proofs pi_i come from one fixed-base MSM call instead of one scalar-multiplication
+    batch and one point sum per item."""
+    if table is not None:
+        pis = commit_g1_many(table, [quotient_by_root(f_coeffs, ident) for ident, _, _ in items])
+    else:
+        pis = [commit_g1(engine, g1, tau_powers, quotient_by_root(f_coeffs, ident)) for ident, _, _ in items]
     P_rows, Q_rows, c2 = [], [], []
-    for ident, C1, C2 in items:
-        pi = commit_g1(engine, g1, tau_powers, quotient_by_root(f_coeffs, ident))
-        P_rows.append(np.stack([np.asarray(D, dtype=np.uint8), pi, np.asarray(sk, dtype=np.uint8)]))
+    for (ident, C1, C2), pi in zip(items, pis):
+        P_rows.append(np.stack([np.asarray(D, dtype=np.uint8), np.asarray(pi, dtype=np.uint8).reshape(64), np.asarray(sk, dtype=np.uint8)]))
         Q_rows.append(np.asarray(C1, dtype=np.uint8).reshape(3, 128))
         c2.append(np.asarray(C2, dtype=np.uint8))
     off = np.arange(0, 3 * len(items) + 1, 3)

@@ -478,3 +478,72 @@ def map_to_g2(u):
     """Tail of bn254.HashToG2: rows of two E2 (128 B) -> ClearCofactor(MapToCurve2(u0) + MapToCurve2(u1))."""
     lib = _lib.load()
     return _map_fields(G2_BYTES, lib.gpbc_g2_map_to_curve_batch, lib.gpbc_g2_map_to_curve_batch_dev, u)
+
+
+# --------------------------------------------------------------------------------------- fixed-base tables / MSM
+class FixedBase:
+    """8-bit window tables of a fixed set of bases kept in HBM (1 MB per G1 base, 2 MB per G2 base): afterwards a term of
+    a sum costs 32 mixed additions and no doublings.  Serves (*G1Affine|*G2Affine).ScalarMultiplicationBase (one base: the
+    generator) and the commitment loops  sum_j [c_j] srs_j  of bibe/afp25_bibe/afp25_bibe_utils.go:44-55.
+
+        fb = FixedBase(bases, g2=False)          # bases: [nbase, 64|128] uint8 (numpy or CUDA tensor)
+        out = fb.msm(scalars)                    # scalars: [n_msm, nbase] ints / [n_msm * nbase, 32] bytes -> [n_msm, 64|128]
+        out = fb.mul(scalars)                    # nbase == 1: out[i] = [scalars[i]] base
+    """
+
+    def __init__(self, bases, g2=False):
+        _ensure_init()
+        self._lib = _lib.load()
+        self.g2 = bool(g2)
+        self.width = G2_BYTES if g2 else G1_BYTES
+        self._h = ctypes.c_void_p()
+        if _is_torch(bases):
+            self.nbase = bases.numel() // self.width
+            _lib.check(self._lib.gpbc_fixed_base_create_dev(ctypes.c_int(1 if g2 else 0), _tptr(bases), _sz(self.nbase),
+                                                            _torch_stream(), ctypes.byref(self._h)))
+            import torch
+            torch.cuda.current_stream().synchronize()            # `bases` may be released by the caller after this returns
+        else:
+            b = _np(bases, self.width)
+            self.nbase = b.size // self.width
+            fn = self._lib.gpbc_g2_fixed_base_create if g2 else self._lib.gpbc_g1_fixed_base_create
+            _lib.check(fn(_ptr(b), _sz(self.nbase), ctypes.byref(self._h)))
+
+    def table_bytes(self):
+        return int(self._lib.gpbc_fixed_base_table_bytes(_sz(self.nbase), ctypes.c_int(1 if self.g2 else 0)))
+
+    def msm(self, scalars):
+        k = scalars_to_bytes(scalars) if not (isinstance(scalars, list) and scalars and isinstance(scalars[0], (list, tuple))) \
+            else scalars_to_bytes([s for row in scalars for s in row])
+        if _is_torch(k):
+            import torch
+            n = k.numel() // (SCALAR_BYTES * self.nbase)
+            out = _tnew(k, n, self.width)
+            wsb = int(self._lib.gpbc_fixed_base_msm_workspace_bytes(self._h, _sz(n)))
+            ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=k.device)
+            _lib.check(self._lib.gpbc_fixed_base_msm_dev(self._h, _tptr(k), _sz(n), _tptr(out), _tptr(ws), _sz(wsb), _torch_stream()))
+            torch.cuda.current_stream().synchronize()            # the workspace is freed on return
+            return out
+        k = _np(k, SCALAR_BYTES)
+        if (k.size // SCALAR_BYTES) % self.nbase:
+            raise ValueError("need nbase = %d scalars per sum" % self.nbase)
+        n = k.size // (SCALAR_BYTES * self.nbase)
+        out = np.empty((n, self.width), dtype=np.uint8)
+        _lib.check(self._lib.gpbc_fixed_base_msm(self._h, _ptr(k), _sz(n), _ptr(out)))
+        return out
+
+    def mul(self, scalars):
+        if self.nbase != 1:
+            raise ValueError("mul() is the single-base form; use msm()")
+        return self.msm(scalars)
+
+    def close(self):
+        if self._h:
+            self._lib.gpbc_fixed_base_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

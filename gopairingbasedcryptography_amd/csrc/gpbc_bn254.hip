@@ -288,6 +288,71 @@ GPBC_KERNEL k_g2_map_fields(const uint8_t *__restrict__ u, uint8_t *__restrict__
     g2_store_aff(out + i * GPBC_G2_BYTES, r);
 }
 
+// ---- fixed-base tables (8-bit windows): entry ((b * 32 + w) * 255 + d - 1) = [d * 2^(8w)] base_b, affine, internal limb
+// form in the 128-byte-aligned row layout of curve29.cuh (tab_store / tab_load).  1 MB per G1 base, 2 MB per G2 base.
+constexpr int FB_WINDOWS = 32, FB_DIGITS = 255, FB_ENTRIES = FB_WINDOWS * FB_DIGITS;
+template <class F> __device__ __forceinline__ void fb_build_lane(const uint8_t *bases, size_t nbase, int32_t *table, uint8_t *base_inf, int32_t *tabws, size_t first, size_t count) {
+    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= count) return;
+    const size_t e = first + t, b = e / FB_ENTRIES;
+    const int rem = (int)(e % FB_ENTRIES), w = rem / FB_DIGITS, d = rem % FB_DIGITS + 1;
+    constexpr size_t PT = sizeof(F) == sizeof(Fe) ? GPBC_G1_BYTES : GPBC_G2_BYTES;
+    const uint8_t *bp = bases + b * PT;
+    AffP<F> base;
+    if constexpr (sizeof(F) == sizeof(Fe)) base = g1_load_aff(bp); else base = g2_load_aff(bp);
+    if (rem == 0) base_inf[b] = base.inf ? 1 : 0;
+    uint32_t k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    k[w >> 2] = (uint32_t)d << (8 * (w & 3));
+    JacP<F> r;
+    scalar_mul29_jac<F>(r, base, k, tabws + t * (size_t)glv_table_dwords<F>());
+    AffP<F> a;
+    jac_to_affine(a, r);
+    tab_store(table + e * (size_t)TabLayout<F>::ENTRY_DWORDS, 0, a);
+}
+GPBC_KERNEL_G1 k_g1_fb_build(const uint8_t *__restrict__ bases, size_t nbase, int32_t *__restrict__ table, uint8_t *__restrict__ base_inf, int32_t *__restrict__ tabws, size_t first, size_t count) {
+    fb_build_lane<Fe>(bases, nbase, table, base_inf, tabws, first, count);
+}
+GPBC_KERNEL k_g2_fb_build(const uint8_t *__restrict__ bases, size_t nbase, int32_t *__restrict__ table, uint8_t *__restrict__ base_inf, int32_t *__restrict__ tabws, size_t first, size_t count) {
+    fb_build_lane<F2>(bases, nbase, table, base_inf, tabws, first, count);
+}
+// multi-scalar multiplication over the tables: lane (c, m) adds the terms of MSM m for bases [c*C, (c+1)*C): 32 mixed
+// additions per term, no doublings.  Partials are written chunk-major (partial[c * n_msm + m]) so that ONE launch of the
+// strided point-sum kernel adds the chunks of every MSM.
+template <class F> __device__ __forceinline__ void fb_msm_lane(const int32_t *table, const uint8_t *base_inf, size_t nbase, const uint8_t *scalars,
+                                                               size_t n_msm, size_t C, size_t n_chunks, uint8_t *partial) {
+    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= n_msm * n_chunks) return;
+    const size_t m = t % n_msm, c = t / n_msm;
+    JacP<F> acc;
+    jac_set_inf(acc);
+    const size_t j1 = (c + 1) * C < nbase ? (c + 1) * C : nbase;
+    for (size_t j = c * C; j < j1; j++) {
+        if (base_inf[j]) continue;
+        uint32_t k[8];
+        load_scalar(k, scalars + (m * nbase + j) * GPBC_SCALAR_BYTES);
+        const int32_t *tb = table + j * (size_t)FB_ENTRIES * TabLayout<F>::ENTRY_DWORDS;
+        for (int w = 0; w < FB_WINDOWS; w++) {
+            const int d = (int)((k[w >> 2] >> (8 * (w & 3))) & 255u);
+            if (d) {
+                AffP<F> e;
+                tab_load(tb + (size_t)(w * FB_DIGITS + d - 1) * TabLayout<F>::ENTRY_DWORDS, 0, e);
+                jac_add_mixed(acc, acc, e);
+            }
+        }
+    }
+    AffP<F> a;
+    jac_to_affine(a, acc);
+    if constexpr (sizeof(F) == sizeof(Fe)) g1_store_aff(partial + t * GPBC_G1_BYTES, a); else g2_store_aff(partial + t * GPBC_G2_BYTES, a);
+}
+GPBC_KERNEL_G1 k_g1_fb_msm(const int32_t *__restrict__ table, const uint8_t *__restrict__ base_inf, size_t nbase, const uint8_t *__restrict__ scalars,
+                           size_t n_msm, size_t C, size_t n_chunks, uint8_t *__restrict__ partial) {
+    fb_msm_lane<Fe>(table, base_inf, nbase, scalars, n_msm, C, n_chunks, partial);
+}
+GPBC_KERNEL k_g2_fb_msm(const int32_t *__restrict__ table, const uint8_t *__restrict__ base_inf, size_t nbase, const uint8_t *__restrict__ scalars,
+                        size_t n_msm, size_t C, size_t n_chunks, uint8_t *__restrict__ partial) {
+    fb_msm_lane<F2>(table, base_inf, nbase, scalars, n_msm, C, n_chunks, partial);
+}
+
 // =============================================================================================== host side
 static thread_local char g_err[512] = "";
 static std::atomic<int> g_device{-1};
@@ -339,7 +404,7 @@ struct DevBuf {
 
 extern "C" {
 
-int gpbc_abi_version(void) { return 3; }
+int gpbc_abi_version(void) { return 4; }
 const char *gpbc_last_error(void) { return g_err; }
 
 int gpbc_device_count(void) {
@@ -782,5 +847,117 @@ int gpbc_g1_map_to_curve_batch(const void *u, size_t n, void *o) { return map_fi
 int gpbc_g2_map_to_curve_batch(const void *u, size_t n, void *o) { return map_fields_host(true, u, n, o); }
 int gpbc_g1_map_to_curve_batch_dev(const void *u, size_t n, void *o, void *st) { return map_fields_dev(false, u, n, o, st); }
 int gpbc_g2_map_to_curve_batch_dev(const void *u, size_t n, void *o, void *st) { return map_fields_dev(true, u, n, o, st); }
+
+// ----------------------------------------------------------------------------------------------- fixed-base tables / MSM
+struct gpbc_fixed_base { int device; int is_g2; size_t nbase; int32_t *table; uint8_t *base_inf; };
+static size_t fb_table_bytes(size_t nbase, int is_g2) {
+    return nbase * (size_t)FB_ENTRIES * sizeof(int32_t) * (is_g2 ? (size_t)TabLayout<F2>::ENTRY_DWORDS : (size_t)TabLayout<Fe>::ENTRY_DWORDS);
+}
+size_t gpbc_fixed_base_table_bytes(size_t nbase, int is_g2) { return fb_table_bytes(nbase, is_g2); }
+int gpbc_fixed_base_create_dev(int is_g2, const void *d_bases, size_t nbase, void *stream, gpbc_fixed_base **out) {
+    if (!out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    *out = nullptr;
+    if (!nbase || !d_bases) return fail(GPBC_ERR_INVALID_ARG, "fixed-base table needs at least one base");
+    TRY(bind_device());
+    hipStream_t st = (hipStream_t)stream;
+    gpbc_fixed_base *h = new gpbc_fixed_base{g_device.load(), is_g2 ? 1 : 0, nbase, nullptr, nullptr};
+    hipError_t e1 = hipMalloc((void **)&h->table, fb_table_bytes(nbase, is_g2));
+    hipError_t e2 = e1 == hipSuccess ? hipMalloc((void **)&h->base_inf, nbase) : e1;
+    if (e1 != hipSuccess || e2 != hipSuccess) {
+        if (h->table) (void)hipFree(h->table);
+        delete h;
+        return fail(GPBC_ERR_HIP, "hipMalloc of a %zu-byte fixed-base table failed", fb_table_bytes(nbase, is_g2));
+    }
+    const size_t total = nbase * (size_t)FB_ENTRIES;
+    const size_t tab_bytes = sizeof(int32_t) * (is_g2 ? (size_t)glv_table_dwords<F2>() : (size_t)glv_table_dwords<Fe>());
+    const size_t chunk = total < SMUL_CHUNK ? total : SMUL_CHUNK;
+    int rc = GPBC_OK;
+    {
+        std::lock_guard<std::mutex> seq(g_ws_seq_mu);
+        int32_t *tabws = nullptr;
+        rc = stream_workspace(st, chunk * tab_bytes, &tabws);
+        for (size_t off = 0; rc == GPBC_OK && off < total; off += chunk) {
+            const size_t m = total - off < chunk ? total - off : chunk;
+            if (is_g2) k_g2_fb_build<<<grid_for(m), BLOCK, 0, st>>>((const uint8_t *)d_bases, nbase, h->table, h->base_inf, tabws, off, m);
+            else k_g1_fb_build<<<grid_for(m), BLOCK, 0, st>>>((const uint8_t *)d_bases, nbase, h->table, h->base_inf, tabws, off, m);
+            rc = check_launch("k_fb_build");
+        }
+    }
+    if (rc != GPBC_OK) { (void)hipFree(h->table); (void)hipFree(h->base_inf); delete h; return rc; }
+    *out = h;
+    return GPBC_OK;
+}
+static int fb_create_host(int is_g2, const void *bases, size_t nbase, gpbc_fixed_base **out) {
+    if (!out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    *out = nullptr;
+    if (!nbase || !bases) return fail(GPBC_ERR_INVALID_ARG, "fixed-base table needs at least one base");
+    TRY(bind_device());
+    DevBuf dB;
+    TRY(dB.upload(bases, nbase * (is_g2 ? GPBC_G2_BYTES : GPBC_G1_BYTES)));
+    TRY(gpbc_fixed_base_create_dev(is_g2, dB.p, nbase, nullptr, out));
+    return sync_default();                                           // the bases buffer is freed on return
+}
+int gpbc_g1_fixed_base_create(const void *bases, size_t nbase, gpbc_fixed_base **out) { return fb_create_host(0, bases, nbase, out); }
+int gpbc_g2_fixed_base_create(const void *bases, size_t nbase, gpbc_fixed_base **out) { return fb_create_host(1, bases, nbase, out); }
+int gpbc_fixed_base_destroy(gpbc_fixed_base *h) {
+    if (!h) return GPBC_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(h->table);
+    (void)hipFree(h->base_inf);
+    delete h;
+    return GPBC_OK;
+}
+static void fb_shape(const gpbc_fixed_base *h, size_t n_msm, size_t *C, size_t *n_chunks) {
+    // aim for >= 32768 lanes; at most 16 terms per lane so the sum tree stays shallow
+    size_t c = (h->nbase * n_msm) / 32768;
+    if (c < 1) c = 1;
+    if (c > 16) c = 16;
+    if (c > h->nbase) c = h->nbase;
+    *C = c;
+    *n_chunks = (h->nbase + c - 1) / c;
+}
+size_t gpbc_fixed_base_msm_workspace_bytes(const gpbc_fixed_base *h, size_t n_msm) {
+    if (!h || !n_msm) return 0;
+    size_t C, n_chunks;
+    fb_shape(h, n_msm, &C, &n_chunks);
+    return n_chunks > 1 ? n_chunks * n_msm * (h->is_g2 ? GPBC_G2_BYTES : GPBC_G1_BYTES) : 0;
+}
+int gpbc_fixed_base_msm_dev(const gpbc_fixed_base *h, const void *d_scalars, size_t n_msm, void *d_out, void *d_workspace, size_t workspace_bytes, void *stream) {
+    if (!h) return fail(GPBC_ERR_INVALID_ARG, "null table handle");
+    if (!n_msm) return GPBC_OK;
+    if (!d_scalars || !d_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    TRY(bind_device());
+    if (g_device.load() != h->device) return fail(GPBC_ERR_INVALID_ARG, "table was built on device %d", h->device);
+    size_t C, n_chunks;
+    fb_shape(h, n_msm, &C, &n_chunks);
+    if (n_chunks > 1 && (!d_workspace || workspace_bytes < gpbc_fixed_base_msm_workspace_bytes(h, n_msm))) return fail(GPBC_ERR_WORKSPACE, "workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    uint8_t *partial = n_chunks > 1 ? (uint8_t *)d_workspace : (uint8_t *)d_out;
+    const size_t lanes = n_msm * n_chunks;
+    if (h->is_g2) k_g2_fb_msm<<<grid_for(lanes), BLOCK, 0, st>>>(h->table, h->base_inf, h->nbase, (const uint8_t *)d_scalars, n_msm, C, n_chunks, partial);
+    else k_g1_fb_msm<<<grid_for(lanes), BLOCK, 0, st>>>(h->table, h->base_inf, h->nbase, (const uint8_t *)d_scalars, n_msm, C, n_chunks, partial);
+    TRY(check_launch("k_fb_msm"));
+    if (n_chunks > 1) {                                              // out[m] = sum over c of partial[c * n_msm + m]
+        if (h->is_g2) k_g2_sum_level<<<grid_for(n_msm), BLOCK, 0, st>>>(partial, lanes, (uint8_t *)d_out, n_msm);
+        else k_g1_sum_level<<<grid_for(n_msm), BLOCK, 0, st>>>(partial, lanes, (uint8_t *)d_out, n_msm);
+        TRY(check_launch("k_sum_level"));
+    }
+    return GPBC_OK;
+}
+int gpbc_fixed_base_msm(const gpbc_fixed_base *h, const void *scalars, size_t n_msm, void *out) {
+    if (!h) return fail(GPBC_ERR_INVALID_ARG, "null table handle");
+    if (!n_msm) return GPBC_OK;
+    if (!scalars || !out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    TRY(bind_device());
+    const size_t pt = h->is_g2 ? GPBC_G2_BYTES : GPBC_G1_BYTES;
+    DevBuf dS, dO, dW;
+    TRY(dS.upload(scalars, n_msm * h->nbase * GPBC_SCALAR_BYTES)); TRY(dO.alloc(n_msm * pt));
+    const size_t wsb = gpbc_fixed_base_msm_workspace_bytes(h, n_msm);
+    TRY(dW.alloc(wsb));
+    TRY(gpbc_fixed_base_msm_dev(h, dS.p, n_msm, dO.p, dW.p, wsb, nullptr));
+    TRY(sync_default());
+    return dO.download(out, n_msm * pt);
+}
 
 }  // extern "C"

@@ -116,6 +116,25 @@ int gpbc_gt_mul_batch_dev(const void *d_a, const void *d_b, size_t n, void *d_ou
 int gpbc_gt_div_batch_dev(const void *d_a, const void *d_b, size_t n, void *d_out, void *stream);
 int gpbc_gt_inverse_batch_dev(const void *d_a, size_t n, void *d_out, void *stream);
 
+/* ---- fixed-base tables and multi-scalar multiplication -----------------------------------------
+ * Sums  out[m] = sum_j [s[m][j]] base_j  over a FIXED set of bases: (*G1Affine).ScalarMultiplicationBase (nbase == 1, the
+ * generator: signature/bls01_signature/bls_signature.go:45, cpabe/bsw07/bsw07_cpabe.go:69-160) and the commitment loops
+ * `for j { t.ScalarMultiplication(&srs[j], c_j); acc.Add(&acc, &t) }` (bibe/afp25_bibe/afp25_bibe_utils.go:44-55).
+ * create builds 8-bit window tables [d * 2^(8w)] base_j (d = 1..255, w = 0..31) in HBM — gpbc_fixed_base_table_bytes():
+ * 1 MB per G1 base, 2 MB per G2 base — after which a term costs 32 mixed additions and no doublings.  Scalars: n_msm rows
+ * of nbase 32-byte little-endian integers (any value < 2^256; no reduction is needed).  The handle is bound to the device
+ * it was built on; msm calls may run concurrently, destroy must not race with them. */
+typedef struct gpbc_fixed_base gpbc_fixed_base;
+size_t gpbc_fixed_base_table_bytes(size_t nbase, int is_g2);
+int gpbc_g1_fixed_base_create(const void *bases, size_t nbase, gpbc_fixed_base **out);
+int gpbc_g2_fixed_base_create(const void *bases, size_t nbase, gpbc_fixed_base **out);
+int gpbc_fixed_base_create_dev(int is_g2, const void *d_bases, size_t nbase, void *stream, gpbc_fixed_base **out);
+int gpbc_fixed_base_msm(const gpbc_fixed_base *table, const void *scalars, size_t n_msm, void *out);
+size_t gpbc_fixed_base_msm_workspace_bytes(const gpbc_fixed_base *table, size_t n_msm);
+int gpbc_fixed_base_msm_dev(const gpbc_fixed_base *table, const void *d_scalars, size_t n_msm, void *d_out,
+                            void *d_workspace, size_t workspace_bytes, void *stream);
+int gpbc_fixed_base_destroy(gpbc_fixed_base *table);
+
 /* ---- wire formats ------------------------------------------------------------------------------
  * Big-endian canonical (non-Montgomery) encodings of gnark-crypto ecc/bn254 marshal.go; the two top bits of the first byte
  * select the form: 00 uncompressed (infinity = all zero), 01 compressed infinity, 10 / 11 compressed with the smaller /

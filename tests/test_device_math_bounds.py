@@ -163,3 +163,27 @@ def test_safegcd_inversion_matches_fermat_and_oracle(hc):
     hc.hc_fp_inv(vp(a), ctypes.c_size_t(len(vals)), vp(o1), vp(o2))
     exp = b"".join(o.fp_to_mont_bytes(pow(v, o.P - 2, o.P)) for v in vals)
     assert o1.tobytes() == exp and o2.tobytes() == exp
+
+
+def test_fixed_base_msm_under_bounds(hc):
+    """The table-build and 32-additions-per-term loop of k_g1_fb_build / k_g1_fb_msm on the host under the bounds
+    harness (a subset of table rows is built; scalars only use digits of that subset), against the oracle."""
+    import random
+    random.seed(12)
+    allowed = [0, 1, 2, 3, 4, 41, 78, 115, 152, 189, 226]
+    def scalar():
+        return sum((random.randrange(256) if w % 5 == 0 else random.choice(allowed)) << (8 * w) for w in range(32))
+    nbase, n_msm = 3, 4
+    bases = [o.g1_mul(o.G1_GEN, 5 + 11 * j) for j in range(nbase)]
+    bases[1] = None                                                     # a base at infinity contributes nothing
+    ks = [[scalar() for _ in range(nbase)] for _ in range(n_msm)]
+    ks[0][0] = 0
+    B = np.frombuffer(b"".join(o.g1_to_bytes(b) for b in bases), dtype=np.uint8).copy()
+    K = np.frombuffer(b"".join(k.to_bytes(32, "little") for row in ks for k in row), dtype=np.uint8).copy()
+    out = np.zeros(n_msm * 64, dtype=np.uint8)
+    hc.hc_g1_fb_msm(vp(B), ctypes.c_size_t(nbase), vp(K), ctypes.c_size_t(n_msm), vp(out))
+    for m in range(n_msm):
+        acc = None
+        for j in range(nbase):
+            acc = o.g1_add(acc, o.g1_mul(bases[j], ks[m][j] % o.R) if bases[j] else None)
+        assert out[64 * m:64 * m + 64].tobytes() == o.g1_to_bytes(acc), m

@@ -220,6 +220,21 @@ def test_cpp_host_mirror_bls_flow(eng, tmp_path):
     assert out.returncode == 0 and "BLS flow OK" in out.stdout, out.stdout + out.stderr
 
 
+def test_concurrent_host_threads(eng, tmp_path):
+    """Six host threads on the host-pointer API at once (shared default stream and internal workspace): every thread
+    gets a lone caller's results."""
+    import subprocess
+    from conftest import ROOT
+    import os
+    exe = str(tmp_path / "test_threads")
+    pkg = os.path.join(ROOT, "gopairingbasedcryptography_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-pthread", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "test_threads.cpp"),
+                           "-L" + pkg, "-lgpbc_bn254", "-Wl,-rpath," + pkg, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "threads OK" in out.stdout, out.stdout + out.stderr
+
+
 def test_large_batch_chunks_and_properties(eng, oracle):
     """BASELINE size (2^20 would take the oracle ~1 min on one core, so 2^18 + 5 pairs here: more than one lines-workspace
     chunk of 262144, ragged tail): HBM-resident path, spot-checked against the oracle at chunk boundaries, plus
@@ -318,6 +333,53 @@ def test_afp25_batched_decrypt_on_gpu(eng, oracle):
     for t, item in enumerate(inst.items):
         assert (out[t] == inst.msgs[t]).all()
         assert (out[t] == inst.reference_shaped_decrypt(oracle, item)).all()
+
+
+def test_fixed_base_msm(eng, oracle, synth):
+    """Fixed-base window tables: single base (ScalarMultiplicationBase) against the oracle with edge scalars, several
+    bases against the variable-base kernels + point sums, G1 and G2, host and device paths, a base at infinity."""
+    import torch
+    g1, g2 = eng.generators()
+    P, Q = synth
+    edge = [0, 1, 2, 255, 256, o.R - 1, o.R, o.R + 1, (1 << 256) - 1, 1 << 255] + [o.bench_scalar("fb", i) for i in range(54)]
+    kb = np.frombuffer(b"".join((k % (1 << 256)).to_bytes(32, "little") for k in edge), dtype=np.uint8)
+    fb1 = eng.FixedBase(g1)
+    assert fb1.table_bytes() == 32 * 255 * 128
+    assert (fb1.mul(kb) == oracle.g1_scalar_mul(g1, kb, threads=8)).all()
+    fb2 = eng.FixedBase(g2, g2=True)
+    assert (fb2.mul(kb) == oracle.g2_scalar_mul(g2, kb, threads=8)).all()
+    # multi-base: 37 bases (one at infinity), 19 sums
+    nb, nm = 37, 19
+    for pts, is_g2, smul, psum, w in ((P, False, eng.g1_scalar_mul, eng.g1_sum, 64), (Q, True, eng.g2_scalar_mul, eng.g2_sum, 128)):
+        bases = np.ascontiguousarray(pts[:nb]).copy()
+        bases[5] = 0
+        ks = scalars("fbm", nb * nm).reshape(nm, nb * 32)
+        fb = eng.FixedBase(bases, g2=is_g2)
+        got = fb.msm(ks)
+        for m in range(nm):
+            want = psum(smul(bases, ks[m]))
+            assert (got[m] == np.asarray(want).reshape(-1)).all(), (is_g2, m)
+        got_dev = fb.msm(torch.from_numpy(ks.copy()).cuda())
+        assert (got_dev.cpu().numpy() == got).all()
+        fb.close()
+    # large single-base batch through the device path (more lanes than one launch wave): every row equals the variable-base kernel
+    n = 1 << 15
+    kd = torch.from_numpy(scalars("fbl", n).copy()).cuda()
+    assert torch.equal(fb1.mul(kd), eng.g1_scalar_mul(torch.from_numpy(g1).cuda(), kd))
+
+
+def test_afp25_openings_by_fixed_base_msm(eng, oracle):
+    """AFP25 batch decryption with the opening proofs from ONE fixed-base MSM over the SRS (afp25.srs_table): same
+    messages, same bits as the per-item path."""
+    from afp25_fixture import Instance
+    from gopairingbasedcryptography_amd import afp25
+    inst = Instance(eng, B=8, n_items=5)
+    table = afp25.srs_table(eng, inst.g1, inst.tau_powers)
+    a = afp25.decrypt_batch(eng, inst.g1, inst.tau_powers, inst.D, inst.f, inst.sk, inst.items, table=table)
+    b = afp25.decrypt_batch(eng, inst.g1, inst.tau_powers, inst.D, inst.f, inst.sk, inst.items)
+    assert (np.asarray(a) == np.asarray(b)).all()
+    for t in range(len(inst.items)):
+        assert (a[t] == inst.msgs[t]).all()
 
 
 # ---------------------------------------------------------------------------------------- wire formats (§8 f-4)

@@ -16,6 +16,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <thread>
+#include <vector>
 
 using namespace gpbc;
 
@@ -214,6 +215,43 @@ void hc_map_fields(int g2, const uint8_t *U, size_t n, uint8_t *out) {
             g2_map_fields(r, f2_load(U + 128 * i), f2_load(U + 128 * i + 64));
             f2_store(out + 128 * i, r.x); f2_store(out + 128 * i + 64, r.y);
         }
+    }
+}
+// fixed-base MSM exactly as k_g1_fb_build / k_g1_fb_msm do it (G1): 8-bit window table of every base, then 32 mixed
+// additions per term; out[m] = sum_j [K[m][j]] B[j]
+void hc_g1_fb_msm(const uint8_t *B, size_t nbase, const uint8_t *K, size_t n_msm, uint8_t *out) {
+    const size_t E = 32 * 255;
+    std::vector<int32_t> table(nbase * E * 32 + 4);
+    int32_t *tb0 = table.data();
+    while (((uintptr_t)tb0) & 15) tb0++;
+    std::vector<uint8_t> inf(nbase);
+    for (size_t b = 0; b < nbase; b++) {
+        AffP<Fe> base{fe_load(B + 64 * b), fe_load(B + 64 * b + 32), bytes_all_zero(B + 64 * b, 16)};
+        inf[b] = base.inf;
+        for (int w = 0; w < 32; w++)
+            for (int d = 1; d <= 255; d += (w % 5 == 0 || d < 4 || d > 252) ? 1 : 37) {     // a subset of the rows is enough for the bounds proof
+                uint32_t k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                k[w >> 2] = (uint32_t)d << (8 * (w & 3));
+                alignas(16) int32_t tab[glv_table_dwords<Fe>()];
+                JacP<Fe> r; scalar_mul29_jac<Fe>(r, base, k, tab);
+                AffP<Fe> a; jac_to_affine(a, r);
+                tab_store(tb0 + ((b * 32 + w) * 255 + d - 1) * 32, 0, a);
+            }
+    }
+    for (size_t m = 0; m < n_msm; m++) {
+        JacP<Fe> acc; jac_set_inf(acc);
+        for (size_t j = 0; j < nbase; j++) {
+            if (inf[j]) continue;
+            uint32_t k[8]; memcpy(k, K + 32 * (m * nbase + j), 32);
+            for (int w = 0; w < 32; w++) {
+                int d = (k[w >> 2] >> (8 * (w & 3))) & 255;
+                if (!d) continue;
+                AffP<Fe> e; tab_load(tb0 + ((j * 32 + w) * 255 + d - 1) * 32, 0, e);
+                jac_add_mixed(acc, acc, e);
+            }
+        }
+        AffP<Fe> a; jac_to_affine(a, acc);
+        fe_store(out + 64 * m, a.x); fe_store(out + 64 * m + 32, a.y);
     }
 }
 // worst-case figures since process start: [max |int64 column|, max limb bound, max value bound (units of p),

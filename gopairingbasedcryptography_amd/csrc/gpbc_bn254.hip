@@ -909,19 +909,21 @@ int gpbc_fixed_base_destroy(gpbc_fixed_base *h) {
     return GPBC_OK;
 }
 static void fb_shape(const gpbc_fixed_base *h, size_t n_msm, size_t *C, size_t *n_chunks) {
-    // aim for >= 32768 lanes; at most 16 terms per lane so the sum tree stays shallow
-    size_t c = (h->nbase * n_msm) / 32768;
+    // enough lanes to fill the chip (>= 131072 = 2048 waves) before a lane takes more than one term; at most 16 terms per lane
+    size_t c = (h->nbase * n_msm) / 131072;
     if (c < 1) c = 1;
     if (c > 16) c = 16;
     if (c > h->nbase) c = h->nbase;
     *C = c;
     *n_chunks = (h->nbase + c - 1) / c;
 }
+// partial sums of every level of the fan-in-16 reduction over the chunks
 size_t gpbc_fixed_base_msm_workspace_bytes(const gpbc_fixed_base *h, size_t n_msm) {
     if (!h || !n_msm) return 0;
-    size_t C, n_chunks;
+    size_t C, n_chunks, total = 0;
     fb_shape(h, n_msm, &C, &n_chunks);
-    return n_chunks > 1 ? n_chunks * n_msm * (h->is_g2 ? GPBC_G2_BYTES : GPBC_G1_BYTES) : 0;
+    for (size_t c = n_chunks; c > 1; c = (c + 15) / 16) total += c * n_msm;
+    return total * (h->is_g2 ? GPBC_G2_BYTES : GPBC_G1_BYTES);
 }
 int gpbc_fixed_base_msm_dev(const gpbc_fixed_base *h, const void *d_scalars, size_t n_msm, void *d_out, void *d_workspace, size_t workspace_bytes, void *stream) {
     if (!h) return fail(GPBC_ERR_INVALID_ARG, "null table handle");
@@ -933,15 +935,23 @@ int gpbc_fixed_base_msm_dev(const gpbc_fixed_base *h, const void *d_scalars, siz
     fb_shape(h, n_msm, &C, &n_chunks);
     if (n_chunks > 1 && (!d_workspace || workspace_bytes < gpbc_fixed_base_msm_workspace_bytes(h, n_msm))) return fail(GPBC_ERR_WORKSPACE, "workspace too small");
     hipStream_t st = (hipStream_t)stream;
+    const size_t pt = h->is_g2 ? GPBC_G2_BYTES : GPBC_G1_BYTES;
     uint8_t *partial = n_chunks > 1 ? (uint8_t *)d_workspace : (uint8_t *)d_out;
     const size_t lanes = n_msm * n_chunks;
     if (h->is_g2) k_g2_fb_msm<<<grid_for(lanes), BLOCK, 0, st>>>(h->table, h->base_inf, h->nbase, (const uint8_t *)d_scalars, n_msm, C, n_chunks, partial);
     else k_g1_fb_msm<<<grid_for(lanes), BLOCK, 0, st>>>(h->table, h->base_inf, h->nbase, (const uint8_t *)d_scalars, n_msm, C, n_chunks, partial);
     TRY(check_launch("k_fb_msm"));
-    if (n_chunks > 1) {                                              // out[m] = sum over c of partial[c * n_msm + m]
-        if (h->is_g2) k_g2_sum_level<<<grid_for(n_msm), BLOCK, 0, st>>>(partial, lanes, (uint8_t *)d_out, n_msm);
-        else k_g1_sum_level<<<grid_for(n_msm), BLOCK, 0, st>>>(partial, lanes, (uint8_t *)d_out, n_msm);
+    // partials are chunk-major (partial[c * n_msm + m]); the strided sum kernel with n_out = c' * n_msm adds, for every m,
+    // the chunks c' + i * c'' — so each launch divides the number of chunks by 16 until one row per sum is left
+    const uint8_t *in = partial;
+    uint8_t *ws = partial + lanes * pt;
+    for (size_t c = n_chunks; c > 1;) {
+        const size_t c2 = (c + 15) / 16;
+        uint8_t *out = c2 == 1 ? (uint8_t *)d_out : ws;
+        if (h->is_g2) k_g2_sum_level<<<grid_for(c2 * n_msm), BLOCK, 0, st>>>(in, c * n_msm, out, c2 * n_msm);
+        else k_g1_sum_level<<<grid_for(c2 * n_msm), BLOCK, 0, st>>>(in, c * n_msm, out, c2 * n_msm);
         TRY(check_launch("k_sum_level"));
+        in = out; ws += c2 * n_msm * pt; c = c2;
     }
     return GPBC_OK;
 }

@@ -365,7 +365,14 @@ def test_fixed_base_msm(eng, oracle, synth):
     # large single-base batch through the device path (more lanes than one launch wave): every row equals the variable-base kernel
     n = 1 << 15
     kd = torch.from_numpy(scalars("fbl", n).copy()).cuda()
-    assert torch.equal(fb1.mul(kd), eng.g1_scalar_mul(torch.from_numpy(g1).cuda(), kd))
+    g1d, g2d = torch.from_numpy(g1).cuda(), torch.from_numpy(g2).cuda()
+    general = eng.g1_scalar_mul(g1d.repeat(n), kd)                      # one base per scalar: the variable-base kernel
+    assert torch.equal(fb1.mul(kd), general)
+    # a shared base with n >= 16384 goes through a transient table inside gpbc_g1/g2_scalar_mul_batch itself
+    assert torch.equal(eng.g1_scalar_mul(g1d, kd), general)
+    assert torch.equal(eng.g2_scalar_mul(g2d, kd), eng.g2_scalar_mul(g2d.repeat(n), kd))
+    zero_base = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    assert not bool(eng.g1_scalar_mul(zero_base, kd).any())             # [k] infinity = infinity
 
 
 def test_afp25_openings_by_fixed_base_msm(eng, oracle):

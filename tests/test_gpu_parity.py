@@ -375,6 +375,22 @@ def test_fixed_base_msm(eng, oracle, synth):
     assert not bool(eng.g1_scalar_mul(zero_base, kd).any())             # [k] infinity = infinity
 
 
+def test_scalar_mul_chunked_batch_against_fixed_base(eng):
+    """More points than one table-workspace chunk (262 144) through the variable-base kernel, checked row by row against
+    an independent kernel: [k_i]([a_i] g1) must equal [k_i a_i mod r] g1 from the fixed-base table path."""
+    import torch
+    n = (1 << 18) + 7
+    g1, _ = eng.generators()
+    a = [o.bench_scalar("ca", i) for i in range(n)]
+    k = [o.bench_scalar("ck", i) for i in range(n)]
+    to_dev = lambda xs: torch.from_numpy(np.frombuffer(b"".join(x.to_bytes(32, "little") for x in xs), dtype=np.uint8).copy()).cuda()
+    fb = eng.FixedBase(g1)
+    bases = fb.mul(to_dev(a))                                            # [n, 64] distinct bases
+    got = eng.g1_scalar_mul(bases, to_dev(k))                            # nbase == n: chunked variable-base launches
+    want = fb.mul(to_dev([x * y % o.R for x, y in zip(a, k)]))
+    assert torch.equal(got, want)
+
+
 def test_afp25_openings_by_fixed_base_msm(eng, oracle):
     """AFP25 batch decryption with the opening proofs from ONE fixed-base MSM over the SRS (afp25.srs_table): same
     messages, same bits as the per-item path."""

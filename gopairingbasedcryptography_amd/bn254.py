@@ -134,7 +134,14 @@ def multi_pair(P, Q, seg_off, out=None, workspace=None):
         if Q.numel() // G2_BYTES != n:
             raise ValueError("invalid inputs sizes")
         if not _is_torch(seg_off):
-            seg_off = torch.as_tensor(np.ascontiguousarray(seg_off, dtype=np.int64), device=P.device)
+            # segment table on the host: the engine can cut segments into chunks that share their Miller squarings
+            seg = np.ascontiguousarray(seg_off, dtype=np.uint64)
+            k = seg.size - 1
+            if k < 1 or int(seg[-1]) != n:
+                raise ValueError("invalid inputs sizes")
+            out = _tnew(P, k, GT_BYTES) if out is None else out
+            _lib.check(lib.gpbc_multi_pair_hostseg_dev(_tptr(P), _tptr(Q), _ptr(seg), _sz(k), _tptr(out), _torch_stream()))
+            return out
         k = seg_off.numel() - 1
         if k < 1 or int(seg_off[0].item()) != 0 or int(seg_off[-1].item()) != n:
             raise ValueError("invalid inputs sizes")          # the segment table must cover exactly the n pairs

@@ -88,6 +88,42 @@ GPBC_KERNEL k_miller_accumulate(const uint8_t *__restrict__ P, const uint8_t *__
     f6_store(f_out + i * GPBC_GT_BYTES + (x.odd ? 192 : 0), h);
 }
 
+// Multi-pairing form of the two phases (host entry gpbc_multi_pair / gpbc_pairing_check): the pairs of a segment are cut
+// into chunks of at most MULTI_CHUNK pairs, one lane pair accumulates a whole chunk with SHARED squarings
+// (miller_accumulate_multi), and the lines workspace is laid out by slot = i * n_chunks + c (pair i of chunk c) so that
+// adjacent lane pairs read adjacent words whatever the chunk lengths are.
+constexpr int MULTI_CHUNK = 8;
+constexpr size_t MULTI_GROUP = 65536;
+GPBC_KERNEL k_miller_lines_chunks(const uint8_t *__restrict__ P, const uint8_t *__restrict__ Q, int32_t *__restrict__ lines,
+                                  const uint64_t *__restrict__ chunk_off, size_t n_chunks, size_t n_slots) {
+    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= n_slots) return;
+    const size_t i = t / n_chunks, c = t % n_chunks;
+    const uint64_t pair = chunk_off[c] + i;
+    if (pair >= chunk_off[c + 1]) return;                      // slot beyond this chunk's length
+    const uint8_t *p = P + pair * GPBC_G1_BYTES, *q = Q + pair * GPBC_G2_BYTES;
+    if (g1_bytes_inf(p) || g2_bytes_inf(q)) return;
+    G1A a{fe_load(p), fe_load(p + 32)};
+    G2A b{f2_load(q), f2_load(q + 64)};
+    int step = 0;
+    miller_lines(a, b, [&](const LineS &l) { line_store(lines, n_slots, t, step++, l); });
+}
+GPBC_KERNEL k_miller_accumulate_chunks(const uint8_t *__restrict__ P, const uint8_t *__restrict__ Q, const int32_t *__restrict__ lines,
+                                       const uint64_t *__restrict__ chunk_off, uint8_t *__restrict__ f_out, size_t n_chunks, size_t n_slots) {
+    size_t lane = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    size_t c = lane >> 1;
+    if (c >= n_chunks) return;
+    PairDpp x{(bool)(lane & 1)};
+    const uint64_t lo = chunk_off[c], hi = chunk_off[c + 1];
+    int vi[MULTI_CHUNK], m = 0;                                // positions of the pairs that have no point at infinity
+    for (uint64_t i = 0; i < hi - lo && i < (uint64_t)MULTI_CHUNK; i++)
+        if (!g1_bytes_inf(P + (lo + i) * GPBC_G1_BYTES) && !g2_bytes_inf(Q + (lo + i) * GPBC_G2_BYTES)) vi[m++] = (int)i;
+    F6 h;
+    if (m == 0) h = f12p_one(x);
+    else h = miller_accumulate_multi(x, m, [&](int p, int li) -> LineS { return line_load(lines, n_slots, (size_t)vi[p] * n_chunks + c, li); });
+    f6_store(f_out + c * GPBC_GT_BYTES + (x.odd ? 192 : 0), h);
+}
+
 GPBC_KERNEL k_final_exp(const uint8_t *f_in, uint8_t *gt_out, size_t n) {
     size_t lane = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     size_t i = lane >> 1;
@@ -668,46 +704,99 @@ static int check_segments(const uint64_t *seg_off, size_t k, size_t *n_pairs) {
     *n_pairs = (size_t)seg_off[k];
     return GPBC_OK;
 }
+// Core of the multi-pairing with the segment table on the HOST and the points in device memory: every segment is cut into
+// chunks of at most L <= MULTI_CHUNK pairs, one lane pair runs the Miller accumulator of a whole chunk with shared
+// squarings (k_miller_accumulate_chunks), the chunk values of each segment are multiplied (one lane per segment) and one
+// final exponentiation per segment follows.  Every pair beyond the first of a chunk saves its 64 Fp12 squarings (~40 % of
+// its accumulator work); a single bn254.Pair call with hundreds of pairs (ibe/bb04_ibe/bb04_ibe.go:213-225: 257; a
+// 256-attribute BSW07 decrypt: 513) still spreads over many lanes.  Synchronises `st` before it returns (its tables and
+// chunk values are released on return).
+static std::atomic<int> g_multi_chunk{0};
+int gpbc_set_multi_pair_chunk(int pairs_per_chunk) {
+    if (pairs_per_chunk < 0 || pairs_per_chunk > MULTI_CHUNK) return fail(GPBC_ERR_INVALID_ARG, "chunk length must be 0 (automatic) .. %d", MULTI_CHUNK);
+    g_multi_chunk.store(pairs_per_chunk);
+    return GPBC_OK;
+}
+static int multi_pair_core(const uint8_t *dP, const uint8_t *dQ, const uint64_t *seg_off, size_t k, size_t n_pairs, uint8_t *dG, uint8_t *dOk, hipStream_t st) {
+    if (n_pairs < 4 * k && g_multi_chunk.load() <= 0) {
+        // Short segments (BLS checks: 2 pairs; AFP25: 3): sharing squarings among two or three pairs saves ~1 ms per 200 000
+        // pairs, less than the extra chunk-product pass costs; one Miller loop per lane pair and one product per segment.
+        DevBuf dSeg, dW;
+        TRY(dSeg.upload(seg_off, (k + 1) * sizeof(uint64_t)));
+        const size_t wsb = gpbc_multi_pair_workspace_bytes(n_pairs, k);
+        TRY(dW.alloc(wsb));
+        TRY(gpbc_multi_pair_dev(dP, dQ, (const uint64_t *)dSeg.p, n_pairs, k, dG, dW.p, wsb, st));
+        if (dOk) {
+            k_gt_is_one<<<grid_for(k), BLOCK, 0, st>>>(dG, dOk, k);
+            TRY(check_launch("k_gt_is_one"));
+        }
+        HIP_TRY(hipStreamSynchronize(st));
+        return GPBC_OK;
+    }
+    // Chunk length L: as long as possible (more shared squarings) while ~131072 lane pairs stay in flight, and at most
+    // MULTI_CHUNK.  Chunks are launched in groups of MULTI_GROUP = 65536 (131072 lanes = 2048 waves: exactly one full round
+    // of two waves per SIMD on 256 CUs — a lane pair here runs for tens of milliseconds, so a partially filled second round
+    // would cost as much as a full one); the slot grid of a group, L x 65536 lines rows, is at most 10 GB.
+    uint64_t L = (n_pairs + 131071) / 131072;
+    if (g_multi_chunk.load() > 0) L = (uint64_t)g_multi_chunk.load();
+    if (L < 1) L = 1;
+    if (L > (uint64_t)MULTI_CHUNK) L = MULTI_CHUNK;
+    std::vector<uint64_t> chunk_off(1, 0), seg_chunk(1, 0);
+    for (size_t j = 0; j < k; j++) {
+        for (uint64_t a = seg_off[j]; a < seg_off[j + 1]; a += L)
+            chunk_off.push_back(a + L < seg_off[j + 1] ? a + L : seg_off[j + 1]);
+        seg_chunk.push_back(chunk_off.size() - 1);
+    }
+    const size_t n_chunks = chunk_off.size() - 1;
+    DevBuf dChunkOff, dSegChunk, dPart;
+    TRY(dChunkOff.upload(chunk_off.data(), chunk_off.size() * sizeof(uint64_t)));
+    TRY(dSegChunk.upload(seg_chunk.data(), seg_chunk.size() * sizeof(uint64_t)));
+    TRY(dPart.alloc(n_chunks * GPBC_GT_BYTES));
+    {
+        std::lock_guard<std::mutex> seq(g_ws_seq_mu);
+        for (size_t cb = 0; cb < n_chunks; cb += MULTI_GROUP) {
+            const size_t g = n_chunks - cb < MULTI_GROUP ? n_chunks - cb : MULTI_GROUP;
+            size_t max_len = 0;
+            for (size_t c = cb; c < cb + g; c++) { size_t len = (size_t)(chunk_off[c + 1] - chunk_off[c]); if (len > max_len) max_len = len; }
+            const size_t n_slots = max_len * g;
+            int32_t *lines = nullptr;
+            TRY(lines_workspace(st, n_slots, &lines));
+            const uint64_t *co = (const uint64_t *)dChunkOff.p + cb;
+            k_miller_lines_chunks<<<grid_for(n_slots), BLOCK, 0, st>>>(dP, dQ, lines, co, g, n_slots);
+            TRY(check_launch("k_miller_lines_chunks"));
+            k_miller_accumulate_chunks<<<grid_for(2 * g), BLOCK, 0, st>>>(dP, dQ, lines, co, dPart.u8() + cb * GPBC_GT_BYTES, g, n_slots);
+            TRY(check_launch("k_miller_accumulate_chunks"));
+        }
+    }
+    k_segment_product<<<grid_for(k), BLOCK, 0, st>>>(dPart.u8(), (const uint64_t *)dSegChunk.p, dG, k, n_chunks);
+    TRY(check_launch("k_segment_product (segments)"));
+    TRY(gpbc_final_exp_dev(dG, k, dG, st));
+    if (dOk) {
+        k_gt_is_one<<<grid_for(k), BLOCK, 0, st>>>(dG, dOk, k);
+        TRY(check_launch("k_gt_is_one"));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    return GPBC_OK;
+}
+int gpbc_multi_pair_hostseg_dev(const void *dP, const void *dQ, const uint64_t *seg_off, size_t k, void *d_gt_out, void *stream) {
+    if (!k) return fail(GPBC_ERR_INVALID_ARG, "invalid inputs sizes");
+    size_t n_pairs = 0;
+    TRY(check_segments(seg_off, k, &n_pairs));
+    if ((n_pairs && (!dP || !dQ)) || !d_gt_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    TRY(bind_device());
+    return multi_pair_core((const uint8_t *)dP, (const uint8_t *)dQ, seg_off, k, n_pairs, (uint8_t *)d_gt_out, nullptr, (hipStream_t)stream);
+}
 static int multi_pair_host(const void *P, const void *Q, const uint64_t *seg_off, size_t k, void *gt_out, uint8_t *ok_out) {
     if (!k) return fail(GPBC_ERR_INVALID_ARG, "invalid inputs sizes");
     size_t n_pairs = 0;
     TRY(check_segments(seg_off, k, &n_pairs));
     if ((n_pairs && (!P || !Q)) || (!gt_out && !ok_out)) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
     TRY(bind_device());
-    DevBuf dP, dQ, dG, dW, dOk, dChunkOff, dSegChunk, dPart;
+    DevBuf dP, dQ, dG, dOk;
     TRY(dP.upload(P, n_pairs * GPBC_G1_BYTES)); TRY(dQ.upload(Q, n_pairs * GPBC_G2_BYTES));
     TRY(dG.alloc(k * GPBC_GT_BYTES));
-    size_t wsb = gpbc_multi_pair_workspace_bytes(n_pairs, k);
-    TRY(dW.alloc(wsb));
-    // The segment table is on the host here, so the per-segment product is done in two levels: chunks of SEG_CHUNK
-    // Miller values (one lane per chunk), then the chunk products of each segment (one lane per segment).  A single
-    // bn254.Pair call with hundreds of pairs (ibe/bb04_ibe/bb04_ibe.go:213-225: 257; a 256-attribute BSW07 decrypt: 513)
-    // then costs ~SEG_CHUNK + len/SEG_CHUNK sequential Fp12 products instead of len.
-    constexpr uint64_t SEG_CHUNK = 16;
-    std::vector<uint64_t> chunk_off(1, 0), seg_chunk(1, 0);
-    for (size_t j = 0; j < k; j++) {
-        for (uint64_t a = seg_off[j]; a < seg_off[j + 1]; a += SEG_CHUNK)
-            chunk_off.push_back(a + SEG_CHUNK < seg_off[j + 1] ? a + SEG_CHUNK : seg_off[j + 1]);
-        seg_chunk.push_back(chunk_off.size() - 1);
-    }
-    size_t n_chunks = chunk_off.size() - 1;
-    TRY(dChunkOff.upload(chunk_off.data(), chunk_off.size() * sizeof(uint64_t)));
-    TRY(dSegChunk.upload(seg_chunk.data(), seg_chunk.size() * sizeof(uint64_t)));
-    TRY(dPart.alloc(n_chunks * GPBC_GT_BYTES));
-    TRY(gpbc_miller_loop_dev(dP.p, dQ.p, n_pairs, dW.p, nullptr));
-    if (n_chunks) {
-        k_segment_product<<<grid_for(n_chunks), BLOCK>>>(dW.u8(), (const uint64_t *)dChunkOff.p, dPart.u8(), n_chunks, n_pairs);
-        TRY(check_launch("k_segment_product (chunks)"));
-    }
-    k_segment_product<<<grid_for(k), BLOCK>>>(dPart.u8(), (const uint64_t *)dSegChunk.p, dG.u8(), k, n_chunks);
-    TRY(check_launch("k_segment_product (segments)"));
-    TRY(gpbc_final_exp_dev(dG.p, k, dG.p, nullptr));
-    if (ok_out) {
-        TRY(dOk.alloc(k));
-        k_gt_is_one<<<grid_for(k), BLOCK>>>(dG.u8(), dOk.u8(), k);
-        TRY(check_launch("k_gt_is_one"));
-    }
-    TRY(sync_default());
+    if (ok_out) TRY(dOk.alloc(k));
+    TRY(multi_pair_core(dP.u8(), dQ.u8(), seg_off, k, n_pairs, dG.u8(), ok_out ? dOk.u8() : nullptr, nullptr));
     if (gt_out) TRY(dG.download(gt_out, k * GPBC_GT_BYTES));
     if (ok_out) TRY(dOk.download(ok_out, k));
     return GPBC_OK;

@@ -30,6 +30,34 @@ template <class X, class Src> GPBC_INLINE F6 miller_accumulate_pair(const X &x, 
     return h;
 }
 
+// Phase B for a PRODUCT of Miller functions on one lane pair: F = prod_p f_p obeys F <- F^2 * prod_p l_p, so the m pairs of
+// a chunk share the 64 squarings (gnark's multi-pairing does the same; the product of Fp12 values is exact, so the result
+// equals multiplying m separately accumulated values bit for bit).  line(p, li) yields line li (0..87, generation order)
+// of pair p; m >= 1 (the caller drops pairs with a point at infinity: their Miller value is one).
+template <class X, class LineAt> GPBC_INLINE F6 miller_accumulate_multi(const X &x, int m, LineAt &&line) {
+    int li = 0;
+    LineS l0 = line(0, li);
+    F6 h = f6_sel(x.odd, F6{l0.c3, l0.c4, f2_zero()}, F6{l0.c0, f2_zero(), f2_zero()});
+    for (int p = 1; p < m; p++) { LineS l = line(p, li); h = f12p_mul_034(x, h, l.c0, l.c3, l.c4); }
+    li++;
+    for (int i = BN254_ATE_NAF_LEN - 2; i >= 0; i--) {
+        if (i != BN254_ATE_NAF_LEN - 2) {
+            h = f12p_sqr(x, h);
+            for (int p = 0; p < m; p++) { LineS l = line(p, li); h = f12p_mul_034(x, h, l.c0, l.c3, l.c4); }
+            li++;
+        }
+        if (ate_naf_digit(i) != 0) {
+            for (int p = 0; p < m; p++) { LineS l = line(p, li); h = f12p_mul_034(x, h, l.c0, l.c3, l.c4); }
+            li++;
+        }
+    }
+    for (int k = 0; k < 2; k++) {
+        for (int p = 0; p < m; p++) { LineS l = line(p, li); h = f12p_mul_034(x, h, l.c0, l.c3, l.c4); }
+        li++;
+    }
+    return h;
+}
+
 // n squarings in place, each value-reduced once on its outputs (its xi products are only normalised)
 template <class X> GPBC_INLINE F6 f12p_cyclo_sqr_n(const X &x, F6 r, int n) {
     for (int i = 0; i < n; i++) r = f12p_cyclo_sqr<true>(x, r);

@@ -98,6 +98,42 @@ def test_multi_pair_ragged_vs_oracle(eng, oracle, synth):
     assert (eng.multi_pair(P[:n], Q[:n], off) == oracle.multi_pair(P[:n], Q[:n], off, threads=8)).all()
 
 
+def test_multi_pair_shared_squarings_chunks(eng, oracle, synth):
+    """Host multi_pair cuts segments into chunks of up to 8 pairs that share the Miller squarings: segment lengths around
+    the chunk size, an empty segment, points at infinity in the first / middle / last position of a chunk and a whole
+    chunk of infinities — against the C restatement, and against the product of single pairings."""
+    P, Q = synth
+    P, Q = P.reshape(-1, 64).copy(), Q.reshape(-1, 128).copy()
+    lens = [1, 7, 8, 9, 40, 0, 33, 16]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    n = int(off[-1])
+    P, Q = P[:n], Q[:n]
+    P[off[2]] = 0                    # first pair of the 8-segment
+    Q[off[3] + 4] = 0                # middle of a chunk
+    P[off[3] + 7] = 0                # last of the first chunk of the 9-segment
+    P[off[6]:off[6] + 16] = 0        # two whole chunks of infinities inside the 33-segment
+    from gopairingbasedcryptography_amd import _lib
+    want = oracle.multi_pair(P, Q, off, threads=8)
+    try:
+        for chunk in (8, 5, 1, 0):                     # forced chunk lengths, then the automatic choice
+            _lib.check(_lib.load().gpbc_set_multi_pair_chunk(chunk))
+            got = eng.multi_pair(P, Q, off)
+            assert (got == want).all(), chunk
+            import torch
+            got_dev = eng.multi_pair(torch.from_numpy(P).cuda(), torch.from_numpy(Q).cuda(), off)      # host table, device points
+            assert (got_dev.cpu().numpy() == want).all(), chunk
+    finally:
+        _lib.load().gpbc_set_multi_pair_chunk(0)
+    single = eng.pair_batch(P, Q)
+    for j, ln in enumerate(lens):
+        acc = np.frombuffer(o.gt_to_bytes(o.F12_ONE), dtype=np.uint8)
+        for i in range(int(off[j]), int(off[j + 1])):
+            acc = eng.gt_mul(acc, single[i])[0]
+        assert (got[j] == acc).all(), j
+    ok = eng.pairing_check_batch(P, Q, off)
+    assert ok.tolist() == [0, 0, 0, 0, 0, 1, 0, 0]          # only the empty product is one
+
+
 def test_bls_verify_flow(eng):
     """signature/bls01_signature/bls_signature_test.go:8-37 shape: sk, pk=[x]g1, sigma=[x]H, PairingCheck."""
     g1, g2 = eng.generators()

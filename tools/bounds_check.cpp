@@ -153,6 +153,26 @@ void hc_pair_lanes(const uint8_t *P, const uint8_t *Q, size_t n, uint8_t *out, i
         t1.join();
     }
 }
+// product of the Miller functions of n pairs on ONE lane pair with shared squarings (k_miller_accumulate_chunks)
+void hc_pair_lanes_multi(const uint8_t *P, const uint8_t *Q, size_t n, uint8_t *out) {
+    std::vector<LineS> lines(n * MILLER_LINES);
+    for (size_t i = 0; i < n; i++) {
+        G1A a{fe_load(P + 64 * i), fe_load(P + 64 * i + 32)};
+        G2A b{f2_load(Q + 128 * i), f2_load(Q + 128 * i + 64)};
+        int cnt = 0;
+        miller_lines(a, b, [&](const LineS &l) { lines[i * MILLER_LINES + cnt++] = l; });
+    }
+    PairRendezvous rv;
+    auto lane = [&](bool odd) {
+        PairHost x{odd, &rv};
+        F6 h = miller_accumulate_multi(x, (int)n, [&](int p, int li) -> LineS { return lines[(size_t)p * MILLER_LINES + li]; });
+        f6_store(out + (odd ? 192 : 0), h);
+        stats_flush();
+    };
+    std::thread t1(lane, true);
+    lane(false);
+    t1.join();
+}
 void hc_gt_pair_ops(const uint8_t *A, const uint8_t *B, size_t n, uint8_t *mul, uint8_t *sqr, uint8_t *csqr, uint8_t *inv, uint8_t *frob1) {
     for (size_t i = 0; i < n; i++) {
         PairRendezvous rv;

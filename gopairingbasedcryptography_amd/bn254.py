@@ -162,6 +162,28 @@ def multi_pair(P, Q, seg_off, out=None, workspace=None):
     return out
 
 
+def multi_pair_fixed_q(P, Q):
+    """k products over ONE shared list of m G2 points: out[j] = Pair(P[j*m:(j+1)*m], Q).  The lines of every Q_i are computed
+    once for all k segments (a decryption key against k ciphertexts; gnark: PrecomputeLines / MillerLoopFixedQ)."""
+    _ensure_init()
+    lib = _lib.load()
+    if _is_torch(P):
+        m = Q.numel() // G2_BYTES
+        n = P.numel() // G1_BYTES
+        if m < 1 or n < m or n % m:
+            raise ValueError("invalid inputs sizes")
+        out = _tnew(P, n // m, GT_BYTES)
+        _lib.check(lib.gpbc_multi_pair_fixed_q_dev(_tptr(P), _tptr(Q), _sz(m), _sz(n // m), _tptr(out), _torch_stream()))
+        return out
+    P, Q = _np(P, G1_BYTES), _np(Q, G2_BYTES)
+    m, n = Q.size // G2_BYTES, P.size // G1_BYTES
+    if m < 1 or n < m or n % m:
+        raise ValueError("invalid inputs sizes")
+    out = np.empty((n // m, GT_BYTES), dtype=np.uint8)
+    _lib.check(lib.gpbc_multi_pair_fixed_q(_ptr(P), _ptr(Q), _sz(m), _sz(n // m), _ptr(out)))
+    return out
+
+
 def pair(P, Q):
     """bn254.Pair(P, Q): the product of the pairings of all (P[i], Q[i]); one 384-byte GT."""
     P, Q = _np(P, G1_BYTES), _np(Q, G2_BYTES)

@@ -98,19 +98,23 @@ def decrypt_batch(engine, folded, d_key, cts, neg_g1):
 
     folded = fold_key(...) result; d_key = D (128 B);  cts = list of dicts with 'c_tilde' (384 B), 'c' (64 B),
     'cy' / 'cy_prime' ({leaf_id: 64 B});  neg_g1 negates an affine G1 point on the host (gnark's G1Affine.Neg).
-    Returns the n messages as an [n,384] array: one multi_pair call (n segments of 2l+1 pairs) and one gt_mul call."""
+    Returns the n messages as an [n,384] array: one fixed-Q multi-pairing call (n segments of 2l+1 pairs against the one
+    folded key) and one gt_mul call."""
     leaf_ids, dj_hat, djp_hat = folded
     l = len(leaf_ids)
     Q_seg = np.concatenate([np.asarray(dj_hat).reshape(l, 128), np.asarray(djp_hat).reshape(l, 128),
                             np.asarray(d_key, dtype=np.uint8).reshape(1, 128)])
-    P_rows, Q_rows, ctil = [], [], []
+    P_rows, ctil = [], []
     for ct in cts:
         P_rows.append(np.stack([np.asarray(ct["cy"][i], dtype=np.uint8) for i in leaf_ids]
                                + [np.asarray(ct["cy_prime"][i], dtype=np.uint8) for i in leaf_ids]
                                + [neg_g1(np.asarray(ct["c"], dtype=np.uint8))]))
-        Q_rows.append(Q_seg)
         ctil.append(np.asarray(ct["c_tilde"], dtype=np.uint8))
     m = 2 * l + 1
-    off = np.arange(0, len(cts) * m + 1, m)
-    X = engine.multi_pair(np.concatenate(P_rows), np.concatenate(Q_rows), off)      # A / e(C, D) per ciphertext
-    return engine.gt_mul(np.stack(ctil), X)
+    if hasattr(engine, "multi_pair_fixed_q"):
+        # the folded key is the same G2 list for every ciphertext: its Miller lines are computed once for the whole batch
+        X = engine.multi_pair_fixed_q(np.concatenate(P_rows), Q_seg)
+    else:
+        off = np.arange(0, len(cts) * m + 1, m)
+        X = engine.multi_pair(np.concatenate(P_rows), np.concatenate([Q_seg] * len(cts)), off)
+    return engine.gt_mul(np.stack(ctil), X)                                          # C~ * A / e(C, D) per ciphertext

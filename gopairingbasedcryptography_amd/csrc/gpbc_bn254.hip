@@ -124,6 +124,57 @@ GPBC_KERNEL k_miller_accumulate_chunks(const uint8_t *__restrict__ P, const uint
     f6_store(f_out + c * GPBC_GT_BYTES + (x.odd ? 192 : 0), h);
 }
 
+// Fixed-Q multi-pairing (gpbc_multi_pair_fixed_q): k segments pair their own m points P[j*m + i] with ONE shared list
+// Q[0..m) — a BSW07 key against k ciphertexts, a public key against k signatures.  The raw line coefficients of every Q_i
+// are computed once (k_q_lines: 88 x 54 int32 per Q_i, laid out [line][word][i]), the P's are converted to internal form
+// once (k_g1_internal), and the accumulator kernel evaluates a line at its own P (two Fp x Fp2 products) right before the
+// sparse multiplication.  Lane pairs are numbered chunk-major (t = c * k + j): the 32 lane pairs of a wave then work on
+// the same Q_i at the same time, so their line loads are one broadcast transaction.
+GPBC_KERNEL k_q_lines(const uint8_t *__restrict__ Q, int32_t *__restrict__ qlines, size_t m) {
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= m) return;
+    const uint8_t *q = Q + i * GPBC_G2_BYTES;
+    if (g2_bytes_inf(q)) return;
+    G2A b{f2_load(q), f2_load(q + 64)};
+    int step = 0;
+    miller_lines_raw(b, [&](const LineE &l) { line_store(qlines, m, i, step++, LineS{l.r0, l.r1, l.r2}); });
+}
+GPBC_KERNEL_G1 k_g1_internal(const uint8_t *__restrict__ P, int32_t *__restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t *pb = P + i * GPBC_G1_BYTES;
+    AffP<Fe> a{fe_load(pb), fe_load(pb + 32), g1_bytes_inf(pb)};
+    int32_t *o = out + i * 20;                                    // x (9), y (9), infinity flag, pad
+#pragma unroll
+    for (int w = 0; w < NL; w++) { o[w] = a.x.v[w]; o[NL + w] = a.y.v[w]; }
+    o[18] = a.inf ? 1 : 0;
+    o[19] = 0;
+}
+GPBC_KERNEL k_miller_accumulate_fixed_q(const int32_t *__restrict__ Pint, const uint8_t *__restrict__ Q, const int32_t *__restrict__ qlines,
+                                        uint8_t *__restrict__ f_out, size_t m, size_t k, size_t L, size_t n_c) {
+    size_t lane = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    size_t t = lane >> 1;
+    if (t >= n_c * k) return;
+    PairDpp x{(bool)(lane & 1)};
+    const size_t c = t / k, j = t % k;
+    const size_t lo = c * L, hi = (c + 1) * L < m ? (c + 1) * L : m;
+    int vi[MULTI_CHUNK], n = 0;
+    for (size_t i = lo; i < hi; i++)
+        if (!Pint[(j * m + i) * 20 + 18] && !g2_bytes_inf(Q + i * GPBC_G2_BYTES)) vi[n++] = (int)i;
+    F6 h;
+    if (n == 0) h = f12p_one(x);
+    else h = miller_accumulate_multi(x, n, [&](int p, int li) -> LineS {
+        const size_t i = (size_t)vi[p];
+        LineS r = line_load(qlines, m, i, li);                    // raw (r0, r1, r2) of Q_i: the same address for the whole wave
+        const int32_t *pp = Pint + (j * m + i) * 20;
+        Fe px, py;
+#pragma unroll
+        for (int w = 0; w < NL; w++) { px.v[w] = pp[w]; py.v[w] = pp[NL + w]; }
+        return LineS{f2_mul_fe(r.c0, py), f2_mul_fe(r.c3, px), r.c4};
+    });
+    f6_store(f_out + (j * n_c + c) * GPBC_GT_BYTES + (x.odd ? 192 : 0), h);     // segment-major: chunks of a segment are adjacent
+}
+
 GPBC_KERNEL k_final_exp(const uint8_t *f_in, uint8_t *gt_out, size_t n) {
     size_t lane = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     size_t i = lane >> 1;
@@ -777,6 +828,47 @@ static int multi_pair_core(const uint8_t *dP, const uint8_t *dQ, const uint64_t 
     }
     HIP_TRY(hipStreamSynchronize(st));
     return GPBC_OK;
+}
+// out[j] = Pair(P[j*m .. (j+1)*m), Q[0 .. m)), j < k.  Synchronises the stream before returning.
+int gpbc_multi_pair_fixed_q_dev(const void *dP, const void *dQ, size_t m, size_t k, void *d_gt_out, void *stream) {
+    if (!k || !m) return fail(GPBC_ERR_INVALID_ARG, "invalid inputs sizes");
+    if (!dP || !dQ || !d_gt_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    TRY(bind_device());
+    hipStream_t st = (hipStream_t)stream;
+    // chunk of the Q list per lane pair: long enough to share squarings, short enough that >= ~65536 lane pairs exist
+    size_t L = (m * k + 65535) / 65536;
+    if (g_multi_chunk.load() > 0) L = (size_t)g_multi_chunk.load();
+    if (L < 1) L = 1;
+    if (L > (size_t)MULTI_CHUNK) L = MULTI_CHUNK;
+    if (L > m) L = m;
+    const size_t n_c = (m + L - 1) / L;
+    DevBuf dLines, dPint, dPart, dSegChunk;
+    TRY(dLines.alloc(m * LINE_BYTES_PER_PAIR));
+    TRY(dPint.alloc(m * k * 20 * sizeof(int32_t)));
+    TRY(dPart.alloc(n_c * k * GPBC_GT_BYTES));
+    std::vector<uint64_t> seg_chunk(k + 1);
+    for (size_t j = 0; j <= k; j++) seg_chunk[j] = j * n_c;
+    TRY(dSegChunk.upload(seg_chunk.data(), seg_chunk.size() * sizeof(uint64_t)));
+    k_q_lines<<<grid_for(m), BLOCK, 0, st>>>((const uint8_t *)dQ, (int32_t *)dLines.p, m);
+    TRY(check_launch("k_q_lines"));
+    k_g1_internal<<<grid_for(m * k), BLOCK, 0, st>>>((const uint8_t *)dP, (int32_t *)dPint.p, m * k);
+    TRY(check_launch("k_g1_internal"));
+    k_miller_accumulate_fixed_q<<<grid_for(2 * n_c * k), BLOCK, 0, st>>>((const int32_t *)dPint.p, (const uint8_t *)dQ, (const int32_t *)dLines.p, dPart.u8(), m, k, L, n_c);
+    TRY(check_launch("k_miller_accumulate_fixed_q"));
+    k_segment_product<<<grid_for(k), BLOCK, 0, st>>>(dPart.u8(), (const uint64_t *)dSegChunk.p, (uint8_t *)d_gt_out, k, n_c * k);
+    TRY(check_launch("k_segment_product"));
+    TRY(gpbc_final_exp_dev(d_gt_out, k, d_gt_out, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return GPBC_OK;
+}
+int gpbc_multi_pair_fixed_q(const void *P, const void *Q, size_t m, size_t k, void *gt_out) {
+    if (!k || !m) return fail(GPBC_ERR_INVALID_ARG, "invalid inputs sizes");
+    if (!P || !Q || !gt_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    TRY(bind_device());
+    DevBuf dP, dQ, dG;
+    TRY(dP.upload(P, m * k * GPBC_G1_BYTES)); TRY(dQ.upload(Q, m * GPBC_G2_BYTES)); TRY(dG.alloc(k * GPBC_GT_BYTES));
+    TRY(gpbc_multi_pair_fixed_q_dev(dP.p, dQ.p, m, k, dG.p, nullptr));
+    return dG.download(gt_out, k * GPBC_GT_BYTES);
 }
 int gpbc_multi_pair_hostseg_dev(const void *dP, const void *dQ, const uint64_t *seg_off, size_t k, void *d_gt_out, void *stream) {
     if (!k) return fail(GPBC_ERR_INVALID_ARG, "invalid inputs sizes");

@@ -85,6 +85,29 @@ template <class Sink> GPBC_INLINE void miller_lines(const G1A &p, const G2A &q, 
     sink(line_scale(l, p));
 }
 
+// The same walk WITHOUT the evaluation point: the raw coefficients (r0, r1, r2) of the 88 lines depend on Q alone, so a
+// Q that is paired with many P's (a decryption key against many ciphertexts, a fixed public key) needs them once.
+template <class Sink> GPBC_INLINE void miller_lines_raw(const G2A &q, Sink &&sink) {
+    G2P t{q.x, q.y, f2_one()};
+    G2A qn{q.x, f2_neg(q.y)};
+    LineE l;
+    for (int i = BN254_ATE_NAF_LEN - 2; i >= 0; i--) {
+        g2_double_step(t, l);
+        sink(l);
+        int d = ate_naf_digit(i);
+        if (d != 0) {
+            g2_add_step(t, l, d > 0 ? q : qn);
+            sink(l);
+        }
+    }
+    G2A q1{f2_mul(f2_conj(q.x), gamma29(1, 2)), f2_mul(f2_conj(q.y), gamma29(1, 3))};
+    G2A q2{f2_mul(q.x, gamma29(2, 2)), f2_neg(f2_mul(q.y, gamma29(2, 3)))};
+    g2_add_step(t, l, q1);
+    sink(l);
+    g2_add_step(t, l, q2);
+    sink(l);
+}
+
 GPBC_INLINE F12 f12_from_line(const LineS &l) {
     return F12{F6{l.c0, f2_zero(), f2_zero()}, F6{l.c3, l.c4, f2_zero()}};
 }

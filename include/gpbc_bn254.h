@@ -78,6 +78,13 @@ int gpbc_multi_pair_dev(const void *dP, const void *dQ, const uint64_t *d_seg_of
  * pair, bit-identical results.  gpbc_multi_pair and gpbc_pairing_check use the same path.  Synchronises
  * `stream` before returning. */
 int gpbc_multi_pair_hostseg_dev(const void *dP, const void *dQ, const uint64_t *seg_off, size_t k, void *d_gt_out, void *stream);
+/* k products over ONE shared list of G2 points: out[j] = Pair(P[j*m .. (j+1)*m), Q[0 .. m)) — a decryption key against k
+ * ciphertexts (access/tree/access_tree_node.go:106-119 under cpabe/bsw07/bsw07_cpabe.go:172-195: the D_j of a key are the
+ * same for every ciphertext), one public key against k signatures.  The line coefficients of each Q_i are computed once
+ * and reused by all k segments (gnark: PrecomputeLines / MillerLoopFixedQ), on top of the shared squarings; results are
+ * bit-identical to gpbc_multi_pair on the replicated list.  P: k*m points, segment-major.  Synchronises `stream`. */
+int gpbc_multi_pair_fixed_q(const void *P, const void *Q, size_t m, size_t k, void *gt_out);
+int gpbc_multi_pair_fixed_q_dev(const void *dP, const void *dQ, size_t m, size_t k, void *d_gt_out, void *stream);
 /* Tuning / test knob of that path: pairs per shared-squaring chunk, 1..8; 0 (default) = chosen from the batch size. */
 int gpbc_set_multi_pair_chunk(int pairs_per_chunk);
 

@@ -134,6 +134,33 @@ def test_multi_pair_shared_squarings_chunks(eng, oracle, synth):
     assert ok.tolist() == [0, 0, 0, 0, 0, 1, 0, 0]          # only the empty product is one
 
 
+def test_multi_pair_fixed_q(eng, oracle, synth):
+    """One shared G2 list against k segments of G1 points (precomputed lines): equal to multi_pair on the replicated list
+    and to the oracle, for forced chunk lengths and the automatic one; infinities on both sides; device path."""
+    import torch
+    from gopairingbasedcryptography_amd import _lib
+    P, Q = synth
+    m, k = 13, 11
+    Qs = Q.reshape(-1, 128)[:m].copy()
+    Ps = P.reshape(-1, 64)[:m * k].copy()
+    Qs[4] = 0                                   # a key component at infinity: skipped by every segment
+    Ps[2 * m + 1] = 0
+    Ps[5 * m:6 * m] = 0                         # a segment with no finite pair: GT one
+    off = np.arange(0, m * k + 1, m).astype(np.uint64)
+    want = oracle.multi_pair(Ps, np.tile(Qs, (k, 1)), off, threads=8)
+    try:
+        for chunk in (8, 3, 1, 0):
+            _lib.check(_lib.load().gpbc_set_multi_pair_chunk(chunk))
+            assert (eng.multi_pair_fixed_q(Ps, Qs) == want).all(), chunk
+            got = eng.multi_pair_fixed_q(torch.from_numpy(Ps).cuda(), torch.from_numpy(Qs).cuda())
+            assert (got.cpu().numpy() == want).all(), chunk
+    finally:
+        _lib.load().gpbc_set_multi_pair_chunk(0)
+    assert want[5].tobytes() == o.gt_to_bytes(o.F12_ONE)
+    with pytest.raises(ValueError):
+        eng.multi_pair_fixed_q(Ps[:m + 1], Qs)
+
+
 def test_bls_verify_flow(eng):
     """signature/bls01_signature/bls_signature_test.go:8-37 shape: sk, pk=[x]g1, sigma=[x]H, PairingCheck."""
     g1, g2 = eng.generators()

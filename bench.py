@@ -251,6 +251,23 @@ def main():
             fbs = bn254.FixedBase(P[:nsrs].contiguous())
             sec["g1_msm256_terms_per_s"] = rate(fbs.msm, ks[:nsrs * nmsm].contiguous()) * (nsrs * nmsm) / B
             fbs.close()
+            # multi-pairing shapes of BASELINE configs 4 and 5 (pairs/s, one final exponentiation per segment)
+            def pairs_rate(fn, n_pairs, *a):
+                fn(*a)
+                barrier()
+                t1 = time.perf_counter()
+                fn(*a)
+                barrier()
+                return n_pairs / (time.perf_counter() - t1)
+            kseg, mseg = 1024, 513                            # a 256-attribute BSW07 decrypt: 513 pairs per ciphertext
+            if B >= kseg * mseg:
+                off = np.arange(0, kseg * mseg + 1, mseg).astype(np.uint64)
+                Pm, Qm = P[:kseg * mseg].contiguous(), Q[:mseg].contiguous()
+                sec["multi_pair_513_fixed_q_pairs_per_s"] = pairs_rate(bn254.multi_pair_fixed_q, kseg * mseg, Pm, Qm)
+                sec["multi_pair_513_pairs_per_s"] = pairs_rate(bn254.multi_pair, kseg * mseg, Pm, Q[:kseg * mseg].contiguous(), off)
+            k3 = min(B // 3, 1 << 17)                         # AFP25 batch decryption: 3 pairs per item
+            off3 = torch.arange(0, 3 * k3 + 1, 3, dtype=torch.int64, device=dev)
+            sec["multi_pair_3_pairs_per_s"] = pairs_rate(bn254.multi_pair, 3 * k3, P[:3 * k3].contiguous(), Q[:3 * k3].contiguous(), off3)
             ne = min(B, 1 << 16)                              # GT.Exp by full-size exponents
             sec["gt_exp_per_s"] = rate(bn254.gt_exp, gt[:ne].contiguous(), ks[:ne].contiguous()) * ne / B
         if world == 1:

@@ -74,17 +74,8 @@ template <class F> GPBC_NOINLINE void map_to_curve_svdw(AffP<F> &out, const F &u
     out.x = x; out.y = y; out.inf = false;
 }
 
-// psi^j on Jacobian coordinates of the twist: (conj^j X * gamma_j,2, conj^j Y * gamma_j,3, conj^j Z)
-GPBC_INLINE JacP<F2> jac_psi(const JacP<F2> &p, int j) {
-    if (p.inf) return p;
-    const bool cj = j & 1;
-    JacP<F2> r;
-    r.x = f2_mul(cj ? f2_conj(p.x) : p.x, gamma29(j, 2));
-    r.y = f2_mul(cj ? f2_conj(p.y) : p.y, gamma29(j, 3));
-    r.z = cj ? f2_conj(p.z) : p.z;
-    r.inf = false;
-    return r;
-}
+// psi^j on Jacobian coordinates of the twist: jac_psi_tw (wire29.cuh)
+GPBC_INLINE JacP<F2> jac_psi(const JacP<F2> &p, int j) { return jac_psi_tw(p, j); }
 // [x]P + psi([3x]P) + psi^2([x]P) + psi^3(P) for an affine twist point P
 GPBC_NOINLINE void g2_clear_cofactor29(JacP<F2> &out, const AffP<F2> &p) {
     constexpr uint64_t X = 4965661367192848881ull;              // BN254 parameter u

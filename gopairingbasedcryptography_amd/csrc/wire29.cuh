@@ -7,7 +7,7 @@
 // Replaces (G1Affine|G2Affine|GT).Marshal / Unmarshal (reference serialization/serialization_curve.go:5-33),
 // G1Affine.Bytes / GT.Bytes (ibe/gentry06_ibe/gentry06_ibe.go:322-324, hash/hash_from_gt.go:5-8).
 // Decoding follows SetBytes: canonical-range check of every coordinate, square root for the compressed forms (error
-// if none), curve / subgroup check (G1: on the curve, cofactor 1; G2: on the twist and [r]Q = infinity).
+// if none), curve / subgroup check (G1: on the curve, cofactor 1; G2: on the twist and in the order-r subgroup).
 #ifndef GPBC_WIRE29_CUH
 #define GPBC_WIRE29_CUH
 #include "curve29.cuh"
@@ -214,17 +214,34 @@ GPBC_INLINE void g2_wire_encode(uint8_t *out, const uint8_t *in, bool compressed
     fe_wire_store(out + 32, x.a0, 0);
     if (!compressed) { fe_wire_store(out + 64, y.a1, 0); fe_wire_store(out + 96, y.a0, 0); }
 }
-// [r]Q == infinity by plain double-and-add (the GLV path of scalar_mul29 assumes Q already lies in the subgroup)
+// Q on the twist lies in the order-r subgroup  <=>  [x+1]Q + psi([x]Q) + psi^2([x]Q) = psi^3([2x]Q)   (x = the BN parameter u;
+// El Housni, Guillevic, Piellard, ePrint 2022/348 §3 and §5.1 — the test gnark-crypto's G2 IsInSubGroup makes).  One 63-bit
+// plain double-and-add instead of the 254-bit [r]Q (the GLV path of scalar_mul29 is not usable here: it presumes
+// membership).  The oracle keeps the definition [r]Q = infinity; tests compare the two on subgroup points, random twist
+// points, points of the cofactor group (including its small prime order 10069) and mixtures.
+GPBC_INLINE JacP<F2> jac_psi_tw(const JacP<F2> &p, int j) {
+    if (p.inf) return p;
+    const bool cj = j & 1;
+    return JacP<F2>{f2_mul(cj ? f2_conj(p.x) : p.x, gamma29(j, 2)), f2_mul(cj ? f2_conj(p.y) : p.y, gamma29(j, 3)), cj ? f2_conj(p.z) : p.z, false};
+}
 GPBC_NOINLINE bool g2_in_subgroup29(const F2 &x, const F2 &y) {
-    constexpr uint32_t R32[8] = GLV_R32;
+    constexpr uint64_t X = 4965661367192848881ull;
     AffP<F2> q{x, y, false};
-    JacP<F2> acc;
-    jac_set_inf(acc);
-    for (int i = 253; i >= 0; i--) {
-        jac_dbl(acc, acc);
-        if ((R32[i >> 5] >> (i & 31)) & 1) jac_add_mixed(acc, acc, q);
+    JacP<F2> xq;
+    jac_set_inf(xq);
+    for (int i = 62; i >= 0; i--) {
+        jac_dbl(xq, xq);
+        if ((X >> i) & 1) jac_add_mixed(xq, xq, q);
     }
-    return acc.inf;
+    JacP<F2> lhs, t, rhs;
+    jac_add_mixed(lhs, xq, q);                                   // [x+1]Q
+    jac_add(lhs, lhs, jac_psi_tw(xq, 1));
+    jac_add(lhs, lhs, jac_psi_tw(xq, 2));
+    jac_dbl(t, xq);
+    rhs = jac_psi_tw(t, 3);
+    if (!rhs.inf) rhs.y = f2_neg(rhs.y);
+    jac_add(t, lhs, rhs);                                        // lhs - rhs
+    return t.inf;
 }
 GPBC_INLINE bool g2_wire_decode(uint8_t *out, const uint8_t *in, int elem_bytes) {
     wire_zero_bytes(out, 128);

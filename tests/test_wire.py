@@ -133,3 +133,36 @@ def test_random_corruption_agrees_with_oracle(hc):
                 pt, good = unm(b)
                 assert int(good) == int(ok[i]), (key, field, i)
                 assert dec[i].tobytes() == to_mem(pt if good else None), (key, field, i)
+
+
+def test_g2_subgroup_test_agrees_with_the_definition(hc):
+    """The device code decides subgroup membership by gnark's endomorphism identity
+    [x+1]Q + psi([x]Q) + psi^2([x]Q) = psi^3([2x]Q); the oracle by the definition [r]Q = infinity.  They must agree on
+    subgroup points, random twist points, points of the cofactor group (order dividing h2 = 2p - r, including its small
+    prime factor 10069) and sums of a subgroup point and a cofactor point."""
+    import random
+    random.seed(2024)
+    h2 = 2 * o.P - o.R
+    assert h2 % 10069 == 0
+
+    def rand_twist():
+        while True:
+            x = (random.randrange(o.P), random.randrange(o.P))
+            y = o.f2_sqrt(o.f2_add(o.f2_mul(o.f2_sqr(x), x), o.B_G2))
+            if y is not None:
+                return (x, y)
+
+    pts = [o.g2_mul(o.G2_GEN, random.randrange(1, o.R)) for _ in range(6)]
+    pts += [rand_twist() for _ in range(6)]
+    cof = [o.g2_mul_plain(rand_twist(), o.R) for _ in range(4)]                      # order divides h2
+    small = [t for t in (o.g2_mul_plain(rand_twist(), (h2 // 10069) * o.R) for _ in range(3)) if t is not None]
+    pts += cof + small
+    pts += [o.g2_add(pts[i], cof[i]) for i in range(4)]                              # subgroup + cofactor component
+    want = [int(o.g2_in_subgroup(p)) for p in pts]
+    assert want[:6] == [1] * 6 and not any(want[6:])
+    for comp, w in ((False, 128), (True, 64)):
+        wire = np.frombuffer(b"".join(o.g2_marshal(p, comp) for p in pts), dtype=np.uint8)
+        dec, ok = _decode(hc, 1, wire, w, len(pts), 128)
+        assert ok.tolist() == want, comp
+        for i, p in enumerate(pts):
+            assert dec[i].tobytes() == o.g2_to_bytes(p if want[i] else None)

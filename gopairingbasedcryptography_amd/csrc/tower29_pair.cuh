@@ -130,8 +130,8 @@ template <bool REDUCE, class X> GPBC_INLINE F6 f12p_cyclo_sqr(const X &x, const 
     F2 pA = x.swap(A), pB = x.swap(B);
     const F2 &psb = sb;
     F2 tt0 = f2_sel(x.odd, pB, f2_norm(f2_add(pB, q0)));
-    F2 tt1 = f2_sel(x.odd, f2_norm(f2_sub(f2_sub(psa, q1), pq0)), f2_norm(f2_add(A, pq0)));
-    F2 tt2 = f2_sel(x.odd, f2_norm(f2_sub(f2_sub(psb, pq2), q0)), f2_norm(f2_add(pA, q1)));
+    F2 tt1 = f2_norm(f2_sel(x.odd, f2_sub(f2_sub(psa, q1), pq0), f2_add(A, pq0)));       // select first: one normalisation, not two
+    F2 tt2 = f2_norm(f2_sel(x.odd, f2_sub(f2_sub(psb, pq2), q0), f2_add(pA, q1)));
     // out = 3 tt -+ 2 own coefficient  (minus on the even lane, plus on the odd lane)
     F6 sgn = f6_sel(x.odd, h, f6_neg(h));
     F6 r{f2_norm(f2_add(f2_dbl(f2_norm(f2_add(tt0, sgn.b0))), tt0)),

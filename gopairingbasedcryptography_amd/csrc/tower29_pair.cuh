@@ -9,7 +9,7 @@
 //   f12 * line  (034-sparse)       both: h*l0 and h*l1 on the lane's own half                 -> 8 F2 products / lane
 //   f12 * f12   (Karatsuba)        even: a0*b0 + diagonal part of the third product,
 //                                  odd:  a1*b1 + cross part of the third product              -> 9 F2 products / lane
-//   cyclotomic square              5 / 4 F2 squarings
+//   cyclotomic square              4.5 F2 squarings / lane (the ninth is split: real part on one lane, imaginary on the other)
 //
 // X is the exchange policy: X::odd (lane parity) and X::swap(F2/F6) -> the partner lane's value.  The device policy
 // uses DPP; tools/bounds_check.cpp runs the two lanes as two host threads with a rendezvous.

@@ -83,3 +83,20 @@ def test_cpp_host_mirror_compiles_and_fails_loudly_without_gpu(lib, tmp_path):
         pytest.skip("GPU present: covered by the gpu-marked test")
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode != 0 and "no CPU fallback" in out.stderr
+
+
+def test_integration_doc_uses_only_declared_symbols():
+    """Every gpbc_* name in INTEGRATION.md (the cgo shim a maintainer would add, and the entry map) is declared in the
+    header, and every declared entry point appears in the document's map."""
+    import re
+    header = open(os.path.join(ROOT, "include", "gpbc_bn254.h")).read()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    declared = set(re.findall(r"\b(gpbc_[a-z0-9_]+)\s*\(", header))
+    used = set(re.findall(r"\b(gpbc_[a-z0-9_]+)\b", doc)) - {"gpbc_bn254", "gpbc_status", "gpbc_fixed_base"}
+    expand = set()
+    for name in used:                                  # the map writes families as `gpbc_x(_dev)` or "gpbc_x_*"
+        expand.add(name)
+    unknown = {n for n in expand if n not in declared and not any(d.startswith(n) for d in declared)}
+    assert not unknown, unknown
+    missing = {d for d in declared if d not in doc and not any(d.startswith(u) and u != d for u in used)}
+    assert not missing, missing

@@ -1,16 +1,22 @@
-"""Compile libgpbc_bn254.so for gfx950 with hipcc (in-tree, next to this file)."""
+"""Compile libgpbc_bn254.so for gfx950 with hipcc (in-tree, next to this file).
+
+Four translation units (csrc/gpbc_core.hip, gpbc_pairing.hip, gpbc_curve.hip, gpbc_wire.hip) are compiled in parallel and
+linked into one shared library; every unit carries its own device code (no relocatable device code is needed: kernels are
+launched from the unit that defines them)."""
 import hashlib
 import os
 import shutil
 import subprocess
+import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgpbc_bn254.so")
 STAMP = os.path.join(HERE, "libgpbc_bn254.buildhash")
-SOURCES = ["gpbc_bn254.hip"]
-HEADERS = ["fe29.cuh", "tower29.cuh", "tower29_pair.cuh", "curve29.cuh", "pairing29.cuh", "pairing29_pair.cuh", "wire29.cuh", "h2c29.cuh", "bn254_constants.cuh", "bn254_constants29.cuh"]
-FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC"]
+SOURCES = ["gpbc_core.hip", "gpbc_pairing.hip", "gpbc_curve.hip", "gpbc_wire.hip"]
+HEADERS = ["gpbc_common.hpp", "fe29.cuh", "tower29.cuh", "tower29_pair.cuh", "curve29.cuh", "pairing29.cuh", "pairing29_pair.cuh",
+           "wire29.cuh", "h2c29.cuh", "bn254_constants.cuh", "bn254_constants29.cuh"]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC"]
 
 
 def _source_hash():
@@ -35,10 +41,26 @@ def build_library(force=False, verbose=False):
     if not force and not _stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    with tempfile.TemporaryDirectory(prefix="gpbc_build_") as tmp:
+        procs = []
+        for s in SOURCES:
+            obj = os.path.join(tmp, s.replace(".hip", ".o"))
+            cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, s), "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((cmd, obj, subprocess.Popen(cmd)))
+        objs = []
+        for cmd, obj, p in procs:
+            if p.wait() != 0:
+                for _, _, q in procs:
+                    if q.poll() is None:
+                        q.kill()
+                raise subprocess.CalledProcessError(p.returncode, cmd)
+            objs.append(obj)
+        link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(link))
+        subprocess.check_call(link)
     with open(STAMP, "w") as f:
         f.write(_source_hash() + "\n")
     return LIB

@@ -19,7 +19,7 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define GPBC_INLINE __host__ __device__ __forceinline__
-#define GPBC_NOINLINE __host__ __device__ __noinline__
+#define GPBC_NOINLINE inline __host__ __device__ __noinline__   /* inline: one definition per translation unit */
 #else
 #define GPBC_INLINE inline
 #define GPBC_NOINLINE

@@ -1,0 +1,94 @@
+// Shared by the translation units of libgpbc_bn254.so (gpbc_core.hip, gpbc_pairing.hip, gpbc_curve.hip, gpbc_wire.hip):
+// launch-bound macros, small device-side load / store helpers, and the host-side plumbing every entry point uses
+// (thread-local error text, device binding, RAII device buffers, the per-stream internal workspace).  The units are compiled
+// separately (each carries its own copy of the device code it needs; no relocatable device code) and linked into one
+// library.
+#ifndef GPBC_COMMON_HPP
+#define GPBC_COMMON_HPP
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+#include "../../include/gpbc_bn254.h"
+#include "curve29.cuh"
+
+using namespace gpbc;
+
+// One batch element per lane.  Inputs/outputs are gnark structs (Montgomery R = 2^256, canonical); each kernel
+// converts to the internal 9 x 29-bit signed-limb form on load and back to canonical bytes on store.
+constexpr int BLOCK = 64;
+#ifndef GPBC_WAVES_PER_SIMD
+#define GPBC_WAVES_PER_SIMD 2
+#endif
+#define GPBC_KERNEL __global__ void __launch_bounds__(BLOCK, GPBC_WAVES_PER_SIMD)
+// G1 arithmetic is light enough on registers for three waves per SIMD (168 VGPRs): measured +12 % over two, while the Fp2 /
+// Fp12 kernels lose 15-75 % to the extra spills (profiles/r01_microbench_valu2.txt explains the gain: a wave issues
+// at most one VALU instruction per ~4.5 cycles, so the 2.4-cycle VOP2 glue only gets cheaper with more waves).
+#ifndef GPBC_WAVES_G1
+#define GPBC_WAVES_G1 3
+#endif
+#define GPBC_KERNEL_G1 __global__ void __launch_bounds__(BLOCK, GPBC_WAVES_G1)
+
+__device__ __forceinline__ bool g1_bytes_inf(const uint8_t *p) { return bytes_all_zero(p, 16); }
+__device__ __forceinline__ bool g2_bytes_inf(const uint8_t *p) { return bytes_all_zero(p, 32); }
+__device__ __forceinline__ void load_scalar(uint32_t k[8], const uint8_t *p) {
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(p);
+#pragma unroll
+    for (int i = 0; i < 8; i++) k[i] = q[i];
+}
+__device__ __forceinline__ AffP<Fe> g1_load_aff(const uint8_t *p) { return AffP<Fe>{fe_load(p), fe_load(p + 32), g1_bytes_inf(p)}; }
+__device__ __forceinline__ AffP<F2> g2_load_aff(const uint8_t *p) { return AffP<F2>{f2_load(p), f2_load(p + 64), g2_bytes_inf(p)}; }
+__device__ __forceinline__ void g1_store_aff(uint8_t *p, const AffP<Fe> &r) { fe_store(p, r.x); fe_store(p + 32, r.y); }
+__device__ __forceinline__ void g2_store_aff(uint8_t *p, const AffP<F2> &r) { f2_store(p, r.x); f2_store(p + 64, r.y); }
+
+// ---- host side
+extern thread_local char g_err[512];
+extern std::atomic<int> g_device;
+int fail(int code, const char *fmt, ...);
+#define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(GPBC_ERR_HIP, "%s failed: %s", #x, hipGetErrorString(e_)); } while (0)
+#define TRY(x) do { int rc_ = (x); if (rc_ != GPBC_OK) return rc_; } while (0)
+int bind_device();
+static inline unsigned grid_for(size_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
+int check_launch(const char *what);
+int sync_default();
+
+// RAII device buffer for the host-pointer entry points
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) {
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+        if (e != hipSuccess) { p = nullptr; return fail(GPBC_ERR_HIP, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
+        return GPBC_OK;
+    }
+    int upload(const void *src, size_t bytes) {
+        TRY(alloc(bytes));
+        if (bytes) HIP_TRY(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+        return GPBC_OK;
+    }
+    int download(void *dst, size_t bytes) const {
+        if (bytes) HIP_TRY(hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost));
+        return GPBC_OK;
+    }
+    uint8_t *u8() const { return static_cast<uint8_t *>(p); }
+};
+
+// Internal workspace: the Miller lines (88 x 54 int32 per pairing) and the per-point GLV tables of the scalar
+// multiplications (2 KB / 4 KB per point).  One grow-only buffer per (device, stream) — calls on one stream are ordered and
+// may share it, calls on different streams get different buffers — and batches are processed in chunks so the footprint
+// stays bounded.
+constexpr size_t MILLER_CHUNK = 262144;                               // pairings per chunk: 4.98 GB of lines
+constexpr size_t SMUL_CHUNK = 262144;                                 // points per chunk: 0.5 GB (G1) / 1 GB (G2) of tables
+constexpr size_t LINE_BYTES_PER_PAIR = (size_t)88 * 54 * sizeof(int32_t);
+// Held while a call enqueues the kernels that share the stream's workspace (lines then accumulate; table build and loop
+// in one kernel): two host threads launching on the same stream must not interleave such sequences.  Enqueueing is
+// asynchronous, so the lock is held for microseconds.
+extern std::mutex g_ws_seq_mu;
+int stream_workspace(hipStream_t stream, size_t bytes, int32_t **out);
+static inline int lines_workspace(hipStream_t stream, size_t pairs, int32_t **out) { return stream_workspace(stream, pairs * LINE_BYTES_PER_PAIR, out); }
+void free_workspaces();
+
+#endif

@@ -1,0 +1,486 @@
+// libgpbc_bn254.so, unit 2 of 4: Miller loop (two phases, single pairs / shared-squaring chunks / fixed Q), final
+// exponentiation, segment products and the GT kernels, with their C-ABI entries (include/gpbc_bn254.h).  gfx950 only.
+#include "gpbc_common.hpp"
+#include "pairing29.cuh"
+#include "pairing29_pair.cuh"
+
+static_assert(LINE_BYTES_PER_PAIR == (size_t)MILLER_LINES * LINE_WORDS * sizeof(int32_t), "lines workspace row size");
+
+// ---- Miller loop, two kernels.  The 88 lines of a pairing depend only on (P, Q), so the G2 arithmetic (phase A)
+// and the Fp12 accumulator (phase B) run as separate kernels, each with its own register budget; the lines travel
+// through an HBM workspace in internal limb form, word-major so that a wave's accesses are contiguous:
+//   lines[(step * 54 + word) * stride + lane]        (19 KB per pairing, streamed once each way)
+__device__ __forceinline__ void line_store(int32_t *__restrict__ buf, size_t stride, size_t lane, int step, const LineS &l) {
+    int32_t *b = buf + (size_t)step * LINE_WORDS * stride + lane;
+    const Fe *fe[6] = {&l.c0.a0, &l.c0.a1, &l.c3.a0, &l.c3.a1, &l.c4.a0, &l.c4.a1};
+#pragma unroll
+    for (int e = 0; e < 6; e++)
+#pragma unroll
+        for (int i = 0; i < NL; i++) b[(size_t)(e * NL + i) * stride] = fe[e]->v[i];
+}
+__device__ __forceinline__ LineS line_load(const int32_t *__restrict__ buf, size_t stride, size_t lane, int step) {
+    const int32_t *b = buf + (size_t)step * LINE_WORDS * stride + lane;
+    LineS l;
+    Fe *fe[6] = {&l.c0.a0, &l.c0.a1, &l.c3.a0, &l.c3.a1, &l.c4.a0, &l.c4.a1};
+#pragma unroll
+    for (int e = 0; e < 6; e++)
+#pragma unroll
+        for (int i = 0; i < NL; i++) fe[e]->v[i] = b[(size_t)(e * NL + i) * stride];
+    return l;
+}
+
+GPBC_KERNEL k_miller_lines(const uint8_t *__restrict__ P, const uint8_t *__restrict__ Q, int32_t *__restrict__ lines, size_t n, size_t stride) {
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t *p = P + i * GPBC_G1_BYTES, *q = Q + i * GPBC_G2_BYTES;
+    if (g1_bytes_inf(p) || g2_bytes_inf(q)) return;          // phase B skips this pair as well
+    G1A a{fe_load(p), fe_load(p + 32)};
+    G2A b{f2_load(q), f2_load(q + 64)};
+    int step = 0;
+    miller_lines(a, b, [&](const LineS &l) { line_store(lines, stride, i, step++, l); });
+}
+
+// Phase B and the final exponentiation run with one pairing per LANE PAIR (even lane: C0, odd lane: C1 of every Fp12
+// value, halves swapped by DPP — tower29_pair.cuh), so a batch of n pairings is a grid of 2n lanes.
+GPBC_KERNEL k_miller_accumulate(const uint8_t *__restrict__ P, const uint8_t *__restrict__ Q, const int32_t *__restrict__ lines,
+                                uint8_t *__restrict__ f_out, size_t n, size_t stride) {
+    size_t lane = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    size_t i = lane >> 1;
+    if (i >= n) return;
+    PairDpp x{(bool)(lane & 1)};
+    const uint8_t *p = P + i * GPBC_G1_BYTES, *q = Q + i * GPBC_G2_BYTES;
+    F6 h;
+    if (g1_bytes_inf(p) || g2_bytes_inf(q)) h = f12p_one(x);
+    else {
+        int step = 0;
+        h = miller_accumulate_pair(x, [&]() -> LineS { return line_load(lines, stride, i, step++); });
+    }
+    f6_store(f_out + i * GPBC_GT_BYTES + (x.odd ? 192 : 0), h);
+}
+
+// Multi-pairing form of the two phases (host entry gpbc_multi_pair / gpbc_pairing_check): the pairs of a segment are cut
+// into chunks of at most MULTI_CHUNK pairs, one lane pair accumulates a whole chunk with SHARED squarings
+// (miller_accumulate_multi), and the lines workspace is laid out by slot = i * n_chunks + c (pair i of chunk c) so that
+// adjacent lane pairs read adjacent words whatever the chunk lengths are.
+constexpr int MULTI_CHUNK = 8;
+constexpr size_t MULTI_GROUP = 65536;
+GPBC_KERNEL k_miller_lines_chunks(const uint8_t *__restrict__ P, const uint8_t *__restrict__ Q, int32_t *__restrict__ lines,
+                                  const uint64_t *__restrict__ chunk_off, size_t n_chunks, size_t n_slots) {
+    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= n_slots) return;
+    const size_t i = t / n_chunks, c = t % n_chunks;
+    const uint64_t pair = chunk_off[c] + i;
+    if (pair >= chunk_off[c + 1]) return;                      // slot beyond this chunk's length
+    const uint8_t *p = P + pair * GPBC_G1_BYTES, *q = Q + pair * GPBC_G2_BYTES;
+    if (g1_bytes_inf(p) || g2_bytes_inf(q)) return;
+    G1A a{fe_load(p), fe_load(p + 32)};
+    G2A b{f2_load(q), f2_load(q + 64)};
+    int step = 0;
+    miller_lines(a, b, [&](const LineS &l) { line_store(lines, n_slots, t, step++, l); });
+}
+GPBC_KERNEL k_miller_accumulate_chunks(const uint8_t *__restrict__ P, const uint8_t *__restrict__ Q, const int32_t *__restrict__ lines,
+                                       const uint64_t *__restrict__ chunk_off, uint8_t *__restrict__ f_out, size_t n_chunks, size_t n_slots) {
+    size_t lane = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    size_t c = lane >> 1;
+    if (c >= n_chunks) return;
+    PairDpp x{(bool)(lane & 1)};
+    const uint64_t lo = chunk_off[c], hi = chunk_off[c + 1];
+    int vi[MULTI_CHUNK], m = 0;                                // positions of the pairs that have no point at infinity
+    for (uint64_t i = 0; i < hi - lo && i < (uint64_t)MULTI_CHUNK; i++)
+        if (!g1_bytes_inf(P + (lo + i) * GPBC_G1_BYTES) && !g2_bytes_inf(Q + (lo + i) * GPBC_G2_BYTES)) vi[m++] = (int)i;
+    F6 h;
+    if (m == 0) h = f12p_one(x);
+    else h = miller_accumulate_multi(x, m, [&](int p, int li) -> LineS { return line_load(lines, n_slots, (size_t)vi[p] * n_chunks + c, li); });
+    f6_store(f_out + c * GPBC_GT_BYTES + (x.odd ? 192 : 0), h);
+}
+
+// Fixed-Q multi-pairing (gpbc_multi_pair_fixed_q): k segments pair their own m points P[j*m + i] with ONE shared list
+// Q[0..m) — a BSW07 key against k ciphertexts, a public key against k signatures.  The raw line coefficients of every Q_i
+// are computed once (k_q_lines: 88 x 54 int32 per Q_i, laid out [line][word][i]), the P's are converted to internal form
+// once (k_g1_internal), and the accumulator kernel evaluates a line at its own P (two Fp x Fp2 products) right before the
+// sparse multiplication.  Lane pairs are numbered chunk-major (t = c * k + j): the 32 lane pairs of a wave then work on
+// the same Q_i at the same time, so their line loads are one broadcast transaction.
+GPBC_KERNEL k_q_lines(const uint8_t *__restrict__ Q, int32_t *__restrict__ qlines, size_t m) {
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= m) return;
+    const uint8_t *q = Q + i * GPBC_G2_BYTES;
+    if (g2_bytes_inf(q)) return;
+    G2A b{f2_load(q), f2_load(q + 64)};
+    int step = 0;
+    miller_lines_raw(b, [&](const LineE &l) { line_store(qlines, m, i, step++, LineS{l.r0, l.r1, l.r2}); });
+}
+GPBC_KERNEL_G1 k_g1_internal(const uint8_t *__restrict__ P, int32_t *__restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t *pb = P + i * GPBC_G1_BYTES;
+    AffP<Fe> a{fe_load(pb), fe_load(pb + 32), g1_bytes_inf(pb)};
+    int32_t *o = out + i * 20;                                    // x (9), y (9), infinity flag, pad
+#pragma unroll
+    for (int w = 0; w < NL; w++) { o[w] = a.x.v[w]; o[NL + w] = a.y.v[w]; }
+    o[18] = a.inf ? 1 : 0;
+    o[19] = 0;
+}
+GPBC_KERNEL k_miller_accumulate_fixed_q(const int32_t *__restrict__ Pint, const uint8_t *__restrict__ Q, const int32_t *__restrict__ qlines,
+                                        uint8_t *__restrict__ f_out, size_t m, size_t k, size_t L, size_t n_c) {
+    size_t lane = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    size_t t = lane >> 1;
+    if (t >= n_c * k) return;
+    PairDpp x{(bool)(lane & 1)};
+    const size_t c = t / k, j = t % k;
+    const size_t lo = c * L, hi = (c + 1) * L < m ? (c + 1) * L : m;
+    int vi[MULTI_CHUNK], n = 0;
+    for (size_t i = lo; i < hi; i++)
+        if (!Pint[(j * m + i) * 20 + 18] && !g2_bytes_inf(Q + i * GPBC_G2_BYTES)) vi[n++] = (int)i;
+    F6 h;
+    if (n == 0) h = f12p_one(x);
+    else h = miller_accumulate_multi(x, n, [&](int p, int li) -> LineS {
+        const size_t i = (size_t)vi[p];
+        LineS r = line_load(qlines, m, i, li);                    // raw (r0, r1, r2) of Q_i: the same address for the whole wave
+        const int32_t *pp = Pint + (j * m + i) * 20;
+        Fe px, py;
+#pragma unroll
+        for (int w = 0; w < NL; w++) { px.v[w] = pp[w]; py.v[w] = pp[NL + w]; }
+        return LineS{f2_mul_fe(r.c0, py), f2_mul_fe(r.c3, px), r.c4};
+    });
+    f6_store(f_out + (j * n_c + c) * GPBC_GT_BYTES + (x.odd ? 192 : 0), h);     // segment-major: chunks of a segment are adjacent
+}
+
+GPBC_KERNEL k_final_exp(const uint8_t *f_in, uint8_t *gt_out, size_t n) {
+    size_t lane = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    size_t i = lane >> 1;
+    if (i >= n) return;
+    PairDpp x{(bool)(lane & 1)};
+    size_t off = i * GPBC_GT_BYTES + (x.odd ? 192 : 0);
+    F6 h = f6_load(f_in + off);
+    f6_store(gt_out + off, final_exp_pair(x, h));
+}
+
+// product of the Miller functions of each segment: thread j multiplies f[seg_off[j] .. seg_off[j+1])
+// (the segment table lives in device memory and cannot be validated by the host without a copy: offsets are clamped to
+// the number of pairs so that a malformed table can never read outside the Miller-value buffer)
+GPBC_KERNEL k_segment_product(const uint8_t *__restrict__ f, const uint64_t *__restrict__ seg_off, uint8_t *__restrict__ out, size_t k, size_t n_pairs) {
+    size_t j = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= k) return;
+    F12 acc = f12_one(), t;
+    uint64_t lo = seg_off[j], hi = seg_off[j + 1];
+    if (hi > n_pairs) hi = n_pairs;
+    if (lo > hi) lo = hi;
+    for (uint64_t i = lo; i < hi; i++) {
+        f12_load(t, f + i * GPBC_GT_BYTES);
+        acc = f12_mul(acc, t);
+    }
+    f12_store(out + j * GPBC_GT_BYTES, acc);
+}
+
+// GT one in gnark bytes: C0.B0.A0 = R mod p, everything else zero
+__global__ void __launch_bounds__(BLOCK) k_gt_is_one(const uint8_t *__restrict__ gt, uint8_t *__restrict__ ok, size_t n) {
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    constexpr uint64_t ONE[4] = BN254_FP_ONE;
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(gt + i * GPBC_GT_BYTES);
+    uint32_t diff = 0;
+    for (int j = 0; j < 8; j++) diff |= w[j] ^ (uint32_t)(ONE[j >> 1] >> ((j & 1) * 32));
+    for (int j = 8; j < 96; j++) diff |= w[j];
+    ok[i] = diff == 0 ? 1 : 0;
+}
+
+// GT.Exp: left-to-right square-and-multiply on a 256-bit plain exponent (k = 0 -> one)
+GPBC_KERNEL k_gt_exp(const uint8_t *__restrict__ x, const uint8_t *__restrict__ kk, uint8_t *__restrict__ out, size_t n) {
+    size_t lane = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    size_t i = lane >> 1;                                   // one Fp12 per lane pair
+    if (i >= n) return;
+    PairDpp px{(bool)(lane & 1)};
+    size_t off = i * GPBC_GT_BYTES + (px.odd ? 192 : 0);
+    uint32_t k[8];
+    load_scalar(k, kk + i * GPBC_SCALAR_BYTES);
+    f6_store(out + off, f12p_exp256(px, f6_load(x + off), k));
+}
+
+// op 0: a*b   1: a*b^-1   2: a^-1
+GPBC_KERNEL k_gt_binary(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, uint8_t *__restrict__ out, size_t n, int op) {
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    F12 x, y, z;
+    f12_load(x, a + i * GPBC_GT_BYTES);
+    if (op == 2) z = f12_inv(x);
+    else {
+        f12_load(y, b + i * GPBC_GT_BYTES);
+        if (op == 1) y = f12_inv(y);
+        z = f12_mul(x, y);
+    }
+    f12_store(out + i * GPBC_GT_BYTES, z);
+}
+
+extern "C" {
+
+int gpbc_miller_loop_dev(const void *dP, const void *dQ, size_t n, void *d_f_out, void *stream) {
+    if (!n) return GPBC_OK;
+    if (!dP || !dQ || !d_f_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    TRY(bind_device());
+    hipStream_t st = (hipStream_t)stream;
+    size_t chunk = n < MILLER_CHUNK ? n : MILLER_CHUNK;
+    std::lock_guard<std::mutex> seq(g_ws_seq_mu);
+    int32_t *lines = nullptr;
+    TRY(lines_workspace(st, chunk, &lines));
+    for (size_t off = 0; off < n; off += chunk) {
+        size_t m = n - off < chunk ? n - off : chunk;
+        const uint8_t *p = (const uint8_t *)dP + off * GPBC_G1_BYTES, *q = (const uint8_t *)dQ + off * GPBC_G2_BYTES;
+        k_miller_lines<<<grid_for(m), BLOCK, 0, st>>>(p, q, lines, m, chunk);
+        TRY(check_launch("k_miller_lines"));
+        k_miller_accumulate<<<grid_for(2 * m), BLOCK, 0, st>>>(p, q, lines, (uint8_t *)d_f_out + off * GPBC_GT_BYTES, m, chunk);
+        TRY(check_launch("k_miller_accumulate"));
+    }
+    return GPBC_OK;
+}
+int gpbc_final_exp_dev(const void *d_f, size_t n, void *d_gt_out, void *stream) {
+    if (!n) return GPBC_OK;
+    if (!d_f || !d_gt_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    TRY(bind_device());
+    k_final_exp<<<grid_for(2 * n), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_f, (uint8_t *)d_gt_out, n);
+    return check_launch("k_final_exp");
+}
+int gpbc_pair_batch_dev(const void *dP, const void *dQ, size_t n, void *d_gt_out, void *stream) {
+    if (!n) return fail(GPBC_ERR_INVALID_ARG, "invalid inputs sizes");
+    TRY(gpbc_miller_loop_dev(dP, dQ, n, d_gt_out, stream));        // f staged in the output buffer
+    return gpbc_final_exp_dev(d_gt_out, n, d_gt_out, stream);      // each lane rewrites its own 384 B
+}
+size_t gpbc_multi_pair_workspace_bytes(size_t n_pairs, size_t k) { (void)k; return n_pairs * GPBC_GT_BYTES; }
+int gpbc_multi_pair_dev(const void *dP, const void *dQ, const uint64_t *d_seg_off, size_t n_pairs, size_t k,
+                        void *d_gt_out, void *d_workspace, size_t workspace_bytes, void *stream) {
+    if (!k) return fail(GPBC_ERR_INVALID_ARG, "invalid inputs sizes");
+    if (!d_seg_off || !d_gt_out || (n_pairs && (!dP || !dQ || !d_workspace))) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    if (workspace_bytes < gpbc_multi_pair_workspace_bytes(n_pairs, k)) return fail(GPBC_ERR_WORKSPACE, "workspace too small");
+    TRY(gpbc_miller_loop_dev(dP, dQ, n_pairs, d_workspace, stream));
+    k_segment_product<<<grid_for(k), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_workspace, d_seg_off, (uint8_t *)d_gt_out, k, n_pairs);
+    TRY(check_launch("k_segment_product"));
+    return gpbc_final_exp_dev(d_gt_out, k, d_gt_out, stream);
+}
+int gpbc_gt_exp_batch_dev(const void *d_x, const void *d_k, size_t n, void *d_out, void *stream) {
+    if (!n) return GPBC_OK;
+    if (!d_x || !d_k || !d_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    TRY(bind_device());
+    k_gt_exp<<<grid_for(2 * n), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_x, (const uint8_t *)d_k, (uint8_t *)d_out, n);
+    return check_launch("k_gt_exp");
+}
+static int gt_binary_dev(int op, const void *a, const void *b, size_t n, void *out, void *stream) {
+    if (!n) return GPBC_OK;
+    if (!a || (op != 2 && !b) || !out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    TRY(bind_device());
+    k_gt_binary<<<grid_for(n), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)a, (const uint8_t *)b, (uint8_t *)out, n, op);
+    return check_launch("k_gt_binary");
+}
+int gpbc_gt_mul_batch_dev(const void *a, const void *b, size_t n, void *o, void *s) { return gt_binary_dev(0, a, b, n, o, s); }
+int gpbc_gt_div_batch_dev(const void *a, const void *b, size_t n, void *o, void *s) { return gt_binary_dev(1, a, b, n, o, s); }
+int gpbc_gt_inverse_batch_dev(const void *a, size_t n, void *o, void *s) { return gt_binary_dev(2, a, nullptr, n, o, s); }
+
+int gpbc_miller_loop(const void *P, const void *Q, size_t n, void *f_out) {
+    if (!n) return GPBC_OK;
+    if (!P || !Q || !f_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    TRY(bind_device());
+    DevBuf dP, dQ, dF;
+    TRY(dP.upload(P, n * GPBC_G1_BYTES)); TRY(dQ.upload(Q, n * GPBC_G2_BYTES)); TRY(dF.alloc(n * GPBC_GT_BYTES));
+    TRY(gpbc_miller_loop_dev(dP.p, dQ.p, n, dF.p, nullptr));
+    TRY(sync_default());
+    return dF.download(f_out, n * GPBC_GT_BYTES);
+}
+int gpbc_final_exp(const void *f, size_t n, void *gt_out) {
+    if (!n) return GPBC_OK;
+    if (!f || !gt_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    TRY(bind_device());
+    DevBuf dF;
+    TRY(dF.upload(f, n * GPBC_GT_BYTES));
+    TRY(gpbc_final_exp_dev(dF.p, n, dF.p, nullptr));
+    TRY(sync_default());
+    return dF.download(gt_out, n * GPBC_GT_BYTES);
+}
+int gpbc_pair_batch(const void *P, const void *Q, size_t n, void *gt_out) {
+    if (!n) return fail(GPBC_ERR_INVALID_ARG, "invalid inputs sizes");
+    if (!P || !Q || !gt_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    TRY(bind_device());
+    DevBuf dP, dQ, dG;
+    TRY(dP.upload(P, n * GPBC_G1_BYTES)); TRY(dQ.upload(Q, n * GPBC_G2_BYTES)); TRY(dG.alloc(n * GPBC_GT_BYTES));
+    TRY(gpbc_pair_batch_dev(dP.p, dQ.p, n, dG.p, nullptr));
+    TRY(sync_default());
+    return dG.download(gt_out, n * GPBC_GT_BYTES);
+}
+static int check_segments(const uint64_t *seg_off, size_t k, size_t *n_pairs) {
+    if (!seg_off) return fail(GPBC_ERR_INVALID_ARG, "null segment table");
+    if (seg_off[0] != 0) return fail(GPBC_ERR_INVALID_ARG, "seg_off[0] must be 0");
+    for (size_t j = 0; j < k; j++)
+        if (seg_off[j + 1] < seg_off[j]) return fail(GPBC_ERR_INVALID_ARG, "segment table not monotone at %zu", j);
+    *n_pairs = (size_t)seg_off[k];
+    return GPBC_OK;
+}
+// Core of the multi-pairing with the segment table on the HOST and the points in device memory: every segment is cut into
+// chunks of at most L <= MULTI_CHUNK pairs, one lane pair runs the Miller accumulator of a whole chunk with shared
+// squarings (k_miller_accumulate_chunks), the chunk values of each segment are multiplied (one lane per segment) and one
+// final exponentiation per segment follows.  Every pair beyond the first of a chunk saves its 64 Fp12 squarings (~40 % of
+// its accumulator work); a single bn254.Pair call with hundreds of pairs (ibe/bb04_ibe/bb04_ibe.go:213-225: 257; a
+// 256-attribute BSW07 decrypt: 513) still spreads over many lanes.  Synchronises `st` before it returns (its tables and
+// chunk values are released on return).
+static std::atomic<int> g_multi_chunk{0};
+int gpbc_set_multi_pair_chunk(int pairs_per_chunk) {
+    if (pairs_per_chunk < 0 || pairs_per_chunk > MULTI_CHUNK) return fail(GPBC_ERR_INVALID_ARG, "chunk length must be 0 (automatic) .. %d", MULTI_CHUNK);
+    g_multi_chunk.store(pairs_per_chunk);
+    return GPBC_OK;
+}
+static int multi_pair_core(const uint8_t *dP, const uint8_t *dQ, const uint64_t *seg_off, size_t k, size_t n_pairs, uint8_t *dG, uint8_t *dOk, hipStream_t st) {
+    if (n_pairs < 4 * k && g_multi_chunk.load() <= 0) {
+        // Short segments (BLS checks: 2 pairs; AFP25: 3): sharing squarings among two or three pairs saves ~1 ms per 200 000
+        // pairs, less than the extra chunk-product pass costs; one Miller loop per lane pair and one product per segment.
+        DevBuf dSeg, dW;
+        TRY(dSeg.upload(seg_off, (k + 1) * sizeof(uint64_t)));
+        const size_t wsb = gpbc_multi_pair_workspace_bytes(n_pairs, k);
+        TRY(dW.alloc(wsb));
+        TRY(gpbc_multi_pair_dev(dP, dQ, (const uint64_t *)dSeg.p, n_pairs, k, dG, dW.p, wsb, st));
+        if (dOk) {
+            k_gt_is_one<<<grid_for(k), BLOCK, 0, st>>>(dG, dOk, k);
+            TRY(check_launch("k_gt_is_one"));
+        }
+        HIP_TRY(hipStreamSynchronize(st));
+        return GPBC_OK;
+    }
+    // Chunk length L: as long as possible (more shared squarings) while ~131072 lane pairs stay in flight, and at most
+    // MULTI_CHUNK.  Chunks are launched in groups of MULTI_GROUP = 65536 (131072 lanes = 2048 waves: exactly one full round
+    // of two waves per SIMD on 256 CUs — a lane pair here runs for tens of milliseconds, so a partially filled second round
+    // would cost as much as a full one); the slot grid of a group, L x 65536 lines rows, is at most 10 GB.
+    uint64_t L = (n_pairs + 131071) / 131072;
+    if (g_multi_chunk.load() > 0) L = (uint64_t)g_multi_chunk.load();
+    if (L < 1) L = 1;
+    if (L > (uint64_t)MULTI_CHUNK) L = MULTI_CHUNK;
+    std::vector<uint64_t> chunk_off(1, 0), seg_chunk(1, 0);
+    for (size_t j = 0; j < k; j++) {
+        for (uint64_t a = seg_off[j]; a < seg_off[j + 1]; a += L)
+            chunk_off.push_back(a + L < seg_off[j + 1] ? a + L : seg_off[j + 1]);
+        seg_chunk.push_back(chunk_off.size() - 1);
+    }
+    const size_t n_chunks = chunk_off.size() - 1;
+    DevBuf dChunkOff, dSegChunk, dPart;
+    TRY(dChunkOff.upload(chunk_off.data(), chunk_off.size() * sizeof(uint64_t)));
+    TRY(dSegChunk.upload(seg_chunk.data(), seg_chunk.size() * sizeof(uint64_t)));
+    TRY(dPart.alloc(n_chunks * GPBC_GT_BYTES));
+    {
+        std::lock_guard<std::mutex> seq(g_ws_seq_mu);
+        for (size_t cb = 0; cb < n_chunks; cb += MULTI_GROUP) {
+            const size_t g = n_chunks - cb < MULTI_GROUP ? n_chunks - cb : MULTI_GROUP;
+            size_t max_len = 0;
+            for (size_t c = cb; c < cb + g; c++) { size_t len = (size_t)(chunk_off[c + 1] - chunk_off[c]); if (len > max_len) max_len = len; }
+            const size_t n_slots = max_len * g;
+            int32_t *lines = nullptr;
+            TRY(lines_workspace(st, n_slots, &lines));
+            const uint64_t *co = (const uint64_t *)dChunkOff.p + cb;
+            k_miller_lines_chunks<<<grid_for(n_slots), BLOCK, 0, st>>>(dP, dQ, lines, co, g, n_slots);
+            TRY(check_launch("k_miller_lines_chunks"));
+            k_miller_accumulate_chunks<<<grid_for(2 * g), BLOCK, 0, st>>>(dP, dQ, lines, co, dPart.u8() + cb * GPBC_GT_BYTES, g, n_slots);
+            TRY(check_launch("k_miller_accumulate_chunks"));
+        }
+    }
+    k_segment_product<<<grid_for(k), BLOCK, 0, st>>>(dPart.u8(), (const uint64_t *)dSegChunk.p, dG, k, n_chunks);
+    TRY(check_launch("k_segment_product (segments)"));
+    TRY(gpbc_final_exp_dev(dG, k, dG, st));
+    if (dOk) {
+        k_gt_is_one<<<grid_for(k), BLOCK, 0, st>>>(dG, dOk, k);
+        TRY(check_launch("k_gt_is_one"));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    return GPBC_OK;
+}
+// out[j] = Pair(P[j*m .. (j+1)*m), Q[0 .. m)), j < k.  Synchronises the stream before returning.
+int gpbc_multi_pair_fixed_q_dev(const void *dP, const void *dQ, size_t m, size_t k, void *d_gt_out, void *stream) {
+    if (!k || !m) return fail(GPBC_ERR_INVALID_ARG, "invalid inputs sizes");
+    if (!dP || !dQ || !d_gt_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    TRY(bind_device());
+    hipStream_t st = (hipStream_t)stream;
+    // chunk of the Q list per lane pair: long enough to share squarings, short enough that >= ~65536 lane pairs exist
+    size_t L = (m * k + 65535) / 65536;
+    if (g_multi_chunk.load() > 0) L = (size_t)g_multi_chunk.load();
+    if (L < 1) L = 1;
+    if (L > (size_t)MULTI_CHUNK) L = MULTI_CHUNK;
+    if (L > m) L = m;
+    const size_t n_c = (m + L - 1) / L;
+    DevBuf dLines, dPint, dPart, dSegChunk;
+    TRY(dLines.alloc(m * LINE_BYTES_PER_PAIR));
+    TRY(dPint.alloc(m * k * 20 * sizeof(int32_t)));
+    TRY(dPart.alloc(n_c * k * GPBC_GT_BYTES));
+    std::vector<uint64_t> seg_chunk(k + 1);
+    for (size_t j = 0; j <= k; j++) seg_chunk[j] = j * n_c;
+    TRY(dSegChunk.upload(seg_chunk.data(), seg_chunk.size() * sizeof(uint64_t)));
+    k_q_lines<<<grid_for(m), BLOCK, 0, st>>>((const uint8_t *)dQ, (int32_t *)dLines.p, m);
+    TRY(check_launch("k_q_lines"));
+    k_g1_internal<<<grid_for(m * k), BLOCK, 0, st>>>((const uint8_t *)dP, (int32_t *)dPint.p, m * k);
+    TRY(check_launch("k_g1_internal"));
+    k_miller_accumulate_fixed_q<<<grid_for(2 * n_c * k), BLOCK, 0, st>>>((const int32_t *)dPint.p, (const uint8_t *)dQ, (const int32_t *)dLines.p, dPart.u8(), m, k, L, n_c);
+    TRY(check_launch("k_miller_accumulate_fixed_q"));
+    k_segment_product<<<grid_for(k), BLOCK, 0, st>>>(dPart.u8(), (const uint64_t *)dSegChunk.p, (uint8_t *)d_gt_out, k, n_c * k);
+    TRY(check_launch("k_segment_product"));
+    TRY(gpbc_final_exp_dev(d_gt_out, k, d_gt_out, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return GPBC_OK;
+}
+int gpbc_multi_pair_fixed_q(const void *P, const void *Q, size_t m, size_t k, void *gt_out) {
+    if (!k || !m) return fail(GPBC_ERR_INVALID_ARG, "invalid inputs sizes");
+    if (!P || !Q || !gt_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    TRY(bind_device());
+    DevBuf dP, dQ, dG;
+    TRY(dP.upload(P, m * k * GPBC_G1_BYTES)); TRY(dQ.upload(Q, m * GPBC_G2_BYTES)); TRY(dG.alloc(k * GPBC_GT_BYTES));
+    TRY(gpbc_multi_pair_fixed_q_dev(dP.p, dQ.p, m, k, dG.p, nullptr));
+    return dG.download(gt_out, k * GPBC_GT_BYTES);
+}
+int gpbc_multi_pair_hostseg_dev(const void *dP, const void *dQ, const uint64_t *seg_off, size_t k, void *d_gt_out, void *stream) {
+    if (!k) return fail(GPBC_ERR_INVALID_ARG, "invalid inputs sizes");
+    size_t n_pairs = 0;
+    TRY(check_segments(seg_off, k, &n_pairs));
+    if ((n_pairs && (!dP || !dQ)) || !d_gt_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    TRY(bind_device());
+    return multi_pair_core((const uint8_t *)dP, (const uint8_t *)dQ, seg_off, k, n_pairs, (uint8_t *)d_gt_out, nullptr, (hipStream_t)stream);
+}
+static int multi_pair_host(const void *P, const void *Q, const uint64_t *seg_off, size_t k, void *gt_out, uint8_t *ok_out) {
+    if (!k) return fail(GPBC_ERR_INVALID_ARG, "invalid inputs sizes");
+    size_t n_pairs = 0;
+    TRY(check_segments(seg_off, k, &n_pairs));
+    if ((n_pairs && (!P || !Q)) || (!gt_out && !ok_out)) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    TRY(bind_device());
+    DevBuf dP, dQ, dG, dOk;
+    TRY(dP.upload(P, n_pairs * GPBC_G1_BYTES)); TRY(dQ.upload(Q, n_pairs * GPBC_G2_BYTES));
+    TRY(dG.alloc(k * GPBC_GT_BYTES));
+    if (ok_out) TRY(dOk.alloc(k));
+    TRY(multi_pair_core(dP.u8(), dQ.u8(), seg_off, k, n_pairs, dG.u8(), ok_out ? dOk.u8() : nullptr, nullptr));
+    if (gt_out) TRY(dG.download(gt_out, k * GPBC_GT_BYTES));
+    if (ok_out) TRY(dOk.download(ok_out, k));
+    return GPBC_OK;
+}
+int gpbc_multi_pair(const void *P, const void *Q, const uint64_t *seg_off, size_t k, void *gt_out) {
+    if (!gt_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    return multi_pair_host(P, Q, seg_off, k, gt_out, nullptr);
+}
+int gpbc_pairing_check(const void *P, const void *Q, const uint64_t *seg_off, size_t k, uint8_t *ok_out) {
+    if (!ok_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    return multi_pair_host(P, Q, seg_off, k, nullptr, ok_out);
+}
+int gpbc_gt_exp_batch(const void *x, const void *k, size_t n, void *out) {
+    if (!n) return GPBC_OK;
+    if (!x || !k || !out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    TRY(bind_device());
+    DevBuf dX, dK, dO;
+    TRY(dX.upload(x, n * GPBC_GT_BYTES)); TRY(dK.upload(k, n * GPBC_SCALAR_BYTES)); TRY(dO.alloc(n * GPBC_GT_BYTES));
+    TRY(gpbc_gt_exp_batch_dev(dX.p, dK.p, n, dO.p, nullptr));
+    TRY(sync_default());
+    return dO.download(out, n * GPBC_GT_BYTES);
+}
+static int gt_binary_host(int op, const void *a, const void *b, size_t n, void *out) {
+    if (!n) return GPBC_OK;
+    if (!a || (op != 2 && !b) || !out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    TRY(bind_device());
+    DevBuf dA, dB, dO;
+    TRY(dA.upload(a, n * GPBC_GT_BYTES));
+    if (op != 2) TRY(dB.upload(b, n * GPBC_GT_BYTES));
+    TRY(dO.alloc(n * GPBC_GT_BYTES));
+    TRY(gt_binary_dev(op, dA.p, dB.p, n, dO.p, nullptr));
+    TRY(sync_default());
+    return dO.download(out, n * GPBC_GT_BYTES);
+}
+int gpbc_gt_mul_batch(const void *a, const void *b, size_t n, void *o) { return gt_binary_host(0, a, b, n, o); }
+int gpbc_gt_div_batch(const void *a, const void *b, size_t n, void *o) { return gt_binary_host(1, a, b, n, o); }
+int gpbc_gt_inverse_batch(const void *a, size_t n, void *o) { return gt_binary_host(2, a, nullptr, n, o); }
+
+}  // extern "C"

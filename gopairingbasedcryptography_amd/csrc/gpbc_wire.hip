@@ -1,0 +1,151 @@
+// libgpbc_bn254.so, unit 4 of 4: gnark wire formats (csrc/wire29.cuh) and the group part of hash to curve
+// (csrc/h2c29.cuh), with their C-ABI entries (include/gpbc_bn254.h).  gfx950 only.
+#include "gpbc_common.hpp"
+#include "wire29.cuh"
+#include "h2c29.cuh"
+
+// ---- wire formats (csrc/wire29.cuh): one element per lane
+GPBC_KERNEL k_g1_encode(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, size_t n, int compressed) {
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    g1_wire_encode(out + i * (compressed ? GPBC_G1_COMPRESSED_BYTES : GPBC_G1_RAW_BYTES), in + i * GPBC_G1_BYTES, compressed != 0);
+}
+GPBC_KERNEL k_g2_encode(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, size_t n, int compressed) {
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    g2_wire_encode(out + i * (compressed ? GPBC_G2_COMPRESSED_BYTES : GPBC_G2_RAW_BYTES), in + i * GPBC_G2_BYTES, compressed != 0);
+}
+GPBC_KERNEL k_gt_encode(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    gt_wire_encode(out + i * GPBC_GT_BYTES, in + i * GPBC_GT_BYTES);
+}
+GPBC_KERNEL k_g1_decode(const uint8_t *__restrict__ in, int elem_bytes, uint8_t *__restrict__ out, uint8_t *__restrict__ ok, size_t n) {
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    ok[i] = g1_wire_decode(out + i * GPBC_G1_BYTES, in + i * (size_t)elem_bytes, elem_bytes) ? 1 : 0;
+}
+GPBC_KERNEL k_g2_decode(const uint8_t *__restrict__ in, int elem_bytes, uint8_t *__restrict__ out, uint8_t *__restrict__ ok, size_t n) {
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    ok[i] = g2_wire_decode(out + i * GPBC_G2_BYTES, in + i * (size_t)elem_bytes, elem_bytes) ? 1 : 0;
+}
+GPBC_KERNEL k_gt_decode(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, uint8_t *__restrict__ ok, size_t n) {
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    ok[i] = gt_wire_decode(out + i * GPBC_GT_BYTES, in + i * GPBC_GT_BYTES) ? 1 : 0;
+}
+
+// ---- hash to curve, group part (csrc/h2c29.cuh): u = n x 2 field elements -> n points
+GPBC_KERNEL k_g1_map_fields(const uint8_t *__restrict__ u, uint8_t *__restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    AffP<Fe> r;
+    g1_map_fields(r, fe_load(u + i * 64), fe_load(u + i * 64 + 32));
+    g1_store_aff(out + i * GPBC_G1_BYTES, r);
+}
+GPBC_KERNEL k_g2_map_fields(const uint8_t *__restrict__ u, uint8_t *__restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    AffP<F2> r;
+    g2_map_fields(r, f2_load(u + i * 128), f2_load(u + i * 128 + 64));
+    g2_store_aff(out + i * GPBC_G2_BYTES, r);
+}
+
+extern "C" {
+
+// ----------------------------------------------------------------------------------------------- wire formats
+// kind 0 = G1, 1 = G2, 2 = GT
+static size_t wire_mem_bytes(int kind) { return kind == 0 ? GPBC_G1_BYTES : kind == 1 ? GPBC_G2_BYTES : GPBC_GT_BYTES; }
+static size_t wire_enc_bytes(int kind, int compressed) {
+    return kind == 0 ? (compressed ? GPBC_G1_COMPRESSED_BYTES : GPBC_G1_RAW_BYTES)
+         : kind == 1 ? (compressed ? GPBC_G2_COMPRESSED_BYTES : GPBC_G2_RAW_BYTES) : GPBC_GT_BYTES;
+}
+static int marshal_dev(int kind, const void *d_in, size_t n, int compressed, void *d_out, void *stream) {
+    if (!n) return GPBC_OK;
+    if (!d_in || !d_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    if (d_in == d_out) return fail(GPBC_ERR_INVALID_ARG, "marshal cannot run in place");
+    TRY(bind_device());
+    hipStream_t st = (hipStream_t)stream;
+    if (kind == 0) k_g1_encode<<<grid_for(n), BLOCK, 0, st>>>((const uint8_t *)d_in, (uint8_t *)d_out, n, compressed);
+    else if (kind == 1) k_g2_encode<<<grid_for(n), BLOCK, 0, st>>>((const uint8_t *)d_in, (uint8_t *)d_out, n, compressed);
+    else k_gt_encode<<<grid_for(n), BLOCK, 0, st>>>((const uint8_t *)d_in, (uint8_t *)d_out, n);
+    return check_launch("wire encode");
+}
+static int unmarshal_dev(int kind, const void *d_in, size_t elem_bytes, size_t n, void *d_out, uint8_t *d_ok, void *stream) {
+    if (kind == 0 && elem_bytes != GPBC_G1_COMPRESSED_BYTES && elem_bytes != GPBC_G1_RAW_BYTES)
+        return fail(GPBC_ERR_INVALID_ARG, "G1 element size must be 32 or 64");
+    if (kind == 1 && elem_bytes != GPBC_G2_COMPRESSED_BYTES && elem_bytes != GPBC_G2_RAW_BYTES)
+        return fail(GPBC_ERR_INVALID_ARG, "G2 element size must be 64 or 128");
+    if (!n) return GPBC_OK;
+    if (!d_in || !d_out || !d_ok) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    if (d_in == d_out) return fail(GPBC_ERR_INVALID_ARG, "unmarshal cannot run in place");
+    TRY(bind_device());
+    hipStream_t st = (hipStream_t)stream;
+    if (kind == 0) k_g1_decode<<<grid_for(n), BLOCK, 0, st>>>((const uint8_t *)d_in, (int)elem_bytes, (uint8_t *)d_out, d_ok, n);
+    else if (kind == 1) k_g2_decode<<<grid_for(n), BLOCK, 0, st>>>((const uint8_t *)d_in, (int)elem_bytes, (uint8_t *)d_out, d_ok, n);
+    else k_gt_decode<<<grid_for(n), BLOCK, 0, st>>>((const uint8_t *)d_in, (uint8_t *)d_out, d_ok, n);
+    return check_launch("wire decode");
+}
+static int marshal_host(int kind, const void *in, size_t n, int compressed, void *out) {
+    if (!n) return GPBC_OK;
+    if (!in || !out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    TRY(bind_device());
+    DevBuf dI, dO;
+    TRY(dI.upload(in, n * wire_mem_bytes(kind))); TRY(dO.alloc(n * wire_enc_bytes(kind, compressed)));
+    TRY(marshal_dev(kind, dI.p, n, compressed, dO.p, nullptr));
+    TRY(sync_default());
+    return dO.download(out, n * wire_enc_bytes(kind, compressed));
+}
+static int unmarshal_host(int kind, const void *in, size_t elem_bytes, size_t n, void *out, uint8_t *ok) {
+    if (n && (!in || !out || !ok)) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    DevBuf dI, dO, dK;
+    if (n) {
+        TRY(bind_device());
+        TRY(dI.upload(in, n * elem_bytes)); TRY(dO.alloc(n * wire_mem_bytes(kind))); TRY(dK.alloc(n));
+    }
+    TRY(unmarshal_dev(kind, dI.p, elem_bytes, n, dO.p, dK.u8(), nullptr));
+    if (!n) return GPBC_OK;
+    TRY(sync_default());
+    TRY(dO.download(out, n * wire_mem_bytes(kind)));
+    return dK.download(ok, n);
+}
+int gpbc_g1_marshal_batch(const void *p, size_t n, int c, void *o) { return marshal_host(0, p, n, c != 0, o); }
+int gpbc_g2_marshal_batch(const void *p, size_t n, int c, void *o) { return marshal_host(1, p, n, c != 0, o); }
+int gpbc_gt_marshal_batch(const void *g, size_t n, void *o) { return marshal_host(2, g, n, 0, o); }
+int gpbc_g1_marshal_batch_dev(const void *p, size_t n, int c, void *o, void *st) { return marshal_dev(0, p, n, c != 0, o, st); }
+int gpbc_g2_marshal_batch_dev(const void *p, size_t n, int c, void *o, void *st) { return marshal_dev(1, p, n, c != 0, o, st); }
+int gpbc_gt_marshal_batch_dev(const void *g, size_t n, void *o, void *st) { return marshal_dev(2, g, n, 0, o, st); }
+int gpbc_g1_unmarshal_batch(const void *in, size_t eb, size_t n, void *o, uint8_t *ok) { return unmarshal_host(0, in, eb, n, o, ok); }
+int gpbc_g2_unmarshal_batch(const void *in, size_t eb, size_t n, void *o, uint8_t *ok) { return unmarshal_host(1, in, eb, n, o, ok); }
+int gpbc_gt_unmarshal_batch(const void *in, size_t n, void *o, uint8_t *ok) { return unmarshal_host(2, in, GPBC_GT_BYTES, n, o, ok); }
+int gpbc_g1_unmarshal_batch_dev(const void *in, size_t eb, size_t n, void *o, uint8_t *ok, void *st) { return unmarshal_dev(0, in, eb, n, o, ok, st); }
+int gpbc_g2_unmarshal_batch_dev(const void *in, size_t eb, size_t n, void *o, uint8_t *ok, void *st) { return unmarshal_dev(1, in, eb, n, o, ok, st); }
+int gpbc_gt_unmarshal_batch_dev(const void *in, size_t n, void *o, uint8_t *ok, void *st) { return unmarshal_dev(2, in, GPBC_GT_BYTES, n, o, ok, st); }
+
+// ----------------------------------------------------------------------------------------------- hash to curve (group part)
+static int map_fields_dev(bool g2, const void *d_u, size_t n, void *d_out, void *stream) {
+    if (!n) return GPBC_OK;
+    if (!d_u || !d_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    TRY(bind_device());
+    if (g2) k_g2_map_fields<<<grid_for(n), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_u, (uint8_t *)d_out, n);
+    else k_g1_map_fields<<<grid_for(n), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_u, (uint8_t *)d_out, n);
+    return check_launch(g2 ? "k_g2_map_fields" : "k_g1_map_fields");
+}
+static int map_fields_host(bool g2, const void *u, size_t n, void *out) {
+    if (!n) return GPBC_OK;
+    if (!u || !out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    TRY(bind_device());
+    size_t pt = g2 ? GPBC_G2_BYTES : GPBC_G1_BYTES;               // two field elements occupy as many bytes as one point
+    DevBuf dU, dO;
+    TRY(dU.upload(u, n * pt)); TRY(dO.alloc(n * pt));
+    TRY(map_fields_dev(g2, dU.p, n, dO.p, nullptr));
+    TRY(sync_default());
+    return dO.download(out, n * pt);
+}
+int gpbc_g1_map_to_curve_batch(const void *u, size_t n, void *o) { return map_fields_host(false, u, n, o); }
+int gpbc_g2_map_to_curve_batch(const void *u, size_t n, void *o) { return map_fields_host(true, u, n, o); }
+int gpbc_g1_map_to_curve_batch_dev(const void *u, size_t n, void *o, void *st) { return map_fields_dev(false, u, n, o, st); }
+int gpbc_g2_map_to_curve_batch_dev(const void *u, size_t n, void *o, void *st) { return map_fields_dev(true, u, n, o, st); }
+
+}  // extern "C"

@@ -177,6 +177,27 @@ def test_bls_verify_flow(eng):
     assert not eng.pairing_check(np.concatenate([pk, g1]), np.concatenate([H_bad, neg_sigma]))
 
 
+def test_zss_signature_identity(eng):
+    """The ZSS verification equation of the reference (signature/zss04_signature/zss04_signature.go:321-341):
+    sigma = [1 / (H(m) + x)] g1, pk = [x] g2, and e(sigma, [H(m)] g2 + pk) must equal e(g1, g2) — for a batch of messages,
+    with the G2 addition done by the engine's point-sum kernel; a signature under another key must fail."""
+    n = 48
+    g1, g2 = eng.generators()
+    x = o.bench_scalar("zss-x", 0)
+    hs = [o.bench_scalar("zss-h", i) for i in range(n)]
+    inv = [pow((h + x) % o.R, -1, o.R) for h in hs]
+    sigma = eng.g1_scalar_mul(g1, inv)
+    pk = eng.g2_scalar_mul(g2, [x])[0]
+    hg2 = eng.g2_scalar_mul(g2, hs)
+    rhs_pts = np.stack([eng.g2_sum(np.concatenate([hg2[i], pk])) for i in range(n)]).reshape(n, 128)
+    lhs = eng.pair_batch(sigma, rhs_pts)
+    e = eng.pair(g1, g2)
+    assert all((lhs[i] == e).all() for i in range(n))
+    other = eng.g2_scalar_mul(g2, [x + 1])[0]
+    bad = eng.pair_batch(sigma[:4], np.stack([eng.g2_sum(np.concatenate([hg2[i], other])) for i in range(4)]).reshape(4, 128))
+    assert not any((bad[i] == e).all() for i in range(4))
+
+
 def test_scalar_mul_golden(eng):
     for name, fn in (("g1_scalar_mul.json", eng.g1_scalar_mul), ("g2_scalar_mul.json", eng.g2_scalar_mul)):
         g = load_golden(name)["cases"]

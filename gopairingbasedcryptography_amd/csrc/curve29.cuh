@@ -312,6 +312,121 @@ template <class F> GPBC_INLINE void scalar_mul29_jac(JacP<F> &acc, const AffP<F>
     }
     if (!acc.inf) acc.z = g_mul(acc.z, W);               // back from the curve scaled by W
 }
+// ------------------------------------------------------------------------------------------- 4-dimensional GLS for G2
+// On the order-r subgroup of the twist the endomorphism psi (untwist, Frobenius, twist) acts as [mu], mu = 6u^2, so
+// k = k0 + k1 mu + k2 mu^2 + k3 mu^3 (mod r) with |k_i| < 2^66 (Galbraith-Scott lattice for BN curves, Babai rounding) and
+// [k]Q = sum [k_i] psi^i(Q): ONE joint loop of ~66 doublings and ~66 mixed additions of T[b0 b1 b2 b3] = sum b_i P_i,
+// P_i = +-psi^i(Q), instead of the 130 doublings + 65 additions of the two-dimensional GLV loop.  All arithmetic on the
+// small results is done modulo 2^96 (the large terms c_j * B_ji cancel).
+struct GlsSplit { uint32_t k[4][3]; bool neg[4]; };
+GPBC_INLINE void gls_split(GlsSplit &o, const uint32_t kin[8]) {
+    constexpr uint32_t R32[8] = GLV_R32, G[4][7] = GLS_G, BM[4][4][3] = GLS_BMAG;
+    constexpr int GN[4] = GLS_GNEG, BN[4][4] = GLS_BNEG;
+    uint32_t k[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) k[i] = kin[i];
+    for (int rep = 0; rep < 6; rep++) {            // k < 2^256 < 6r: reduce to [0, r)
+        uint32_t d[8];
+        uint64_t borrow = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { uint64_t t = (uint64_t)k[i] - R32[i] - borrow; d[i] = (uint32_t)t; borrow = (t >> 32) & 1; }
+#pragma unroll
+        for (int i = 0; i < 8; i++) k[i] = borrow ? k[i] : d[i];
+    }
+    uint32_t c[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        uint32_t p[11];
+        mp_mul<8, 7, 11>(p, k, G[j]);              // c_j = (k * g_j) >> 256, needed modulo 2^96 only
+        c[j][0] = p[8]; c[j][1] = p[9]; c[j][2] = p[10];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uint32_t acc[3] = {i == 0 ? k[0] : 0u, i == 0 ? k[1] : 0u, i == 0 ? k[2] : 0u};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint32_t t[3], r[3];
+            mp_mul<3, 3, 3>(t, c[j], BM[j][i]);
+            const bool plus = (GN[j] != 0) != (BN[j][i] != 0);     // acc -= sign(c_j) sign(B_ji) |c_j| |B_ji|
+            if (plus) {
+                uint64_t cy = 0;
+#pragma unroll
+                for (int w = 0; w < 3; w++) { uint64_t v = (uint64_t)acc[w] + t[w] + cy; r[w] = (uint32_t)v; cy = v >> 32; }
+            } else mp_sub<3>(r, acc, t);
+            acc[0] = r[0]; acc[1] = r[1]; acc[2] = r[2];
+        }
+        o.neg[i] = (acc[2] >> 31) != 0;
+        if (o.neg[i]) {
+            uint32_t z[3] = {0, 0, 0}, r[3];
+            mp_sub<3>(r, z, acc);
+            acc[0] = r[0]; acc[1] = r[1]; acc[2] = r[2];
+        }
+        o.k[i][0] = acc[0]; o.k[i][1] = acc[1]; o.k[i][2] = acc[2];
+    }
+}
+// table index = b0 + 2 b1 + 4 b2 + 8 b3; entries brought to one common Z like glv_table29 (rows of the same 128-byte layout)
+GPBC_NOINLINE void gls_table29(int32_t *tab, F2 &W, const AffP<F2> (&P)[4]) {
+    F2 one = f2_one();
+    // J[e], e = 0..10: the 11 entries with two or more points, in increasing index order
+    static constexpr int IDX[11] = {3, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15};
+    JacP<F2> J[11];
+    auto single = [&](int i) { return JacP<F2>{P[i].x, P[i].y, one, false}; };
+    jac_add_mixed(J[0], single(0), P[1]);           // 3  = P0+P1
+    jac_add_mixed(J[1], single(0), P[2]);           // 5  = P0+P2
+    jac_add_mixed(J[2], single(1), P[2]);           // 6  = P1+P2
+    jac_add_mixed(J[3], J[0], P[2]);                // 7  = P0+P1+P2
+    jac_add_mixed(J[4], single(0), P[3]);           // 9  = P0+P3
+    jac_add_mixed(J[5], single(1), P[3]);           // 10 = P1+P3
+    jac_add_mixed(J[6], J[0], P[3]);                // 11 = P0+P1+P3
+    jac_add_mixed(J[7], single(2), P[3]);           // 12 = P2+P3
+    jac_add_mixed(J[8], J[1], P[3]);                // 13 = P0+P2+P3
+    jac_add_mixed(J[9], J[2], P[3]);                // 14 = P1+P2+P3
+    jac_add_mixed(J[10], J[3], P[3]);               // 15 = all four
+    F2 pre[11], l[11];
+    F2 run = one;
+    for (int i = 0; i < 11; i++) { pre[i] = run; run = f2_mul(run, J[i].z); }
+    W = run;
+    run = one;
+    for (int i = 10; i >= 0; i--) { l[i] = f2_mul(pre[i], run); run = f2_mul(run, J[i].z); }
+    for (int i = 0; i < 11; i++) {
+        F2 l2 = f2_sqr(l[i]), l3 = f2_mul(l2, l[i]);
+        tab_store(tab, IDX[i], AffP<F2>{f2_mul(J[i].x, l2), f2_mul(J[i].y, l3), false});
+    }
+    F2 w2 = f2_sqr(W), w3 = f2_mul(w2, W);
+    for (int i = 0; i < 4; i++) tab_store(tab, 1 << i, AffP<F2>{f2_mul(P[i].x, w2), f2_mul(P[i].y, w3), false});
+}
+GPBC_INLINE void scalar_mul29_gls(JacP<F2> &acc, const AffP<F2> &base, const uint32_t k[8], int32_t *tab) {
+    GlsSplit s;
+    gls_split(s, k);
+    jac_set_inf(acc);
+    int top = 95;
+    while (top >= 0 && !(((s.k[0][top >> 5] | s.k[1][top >> 5] | s.k[2][top >> 5] | s.k[3][top >> 5]) >> (top & 31)) & 1)) top--;
+    if (base.inf || top < 0) return;
+    AffP<F2> P[4];
+    P[0] = AffP<F2>{base.x, s.neg[0] ? f2_neg(base.y) : base.y, false};
+    for (int i = 1; i < 4; i++) {
+        const bool cj = i & 1;
+        F2 y = f2_mul(cj ? f2_conj(base.y) : base.y, gamma29(i, 3));
+        P[i] = AffP<F2>{f2_mul(cj ? f2_conj(base.x) : base.x, gamma29(i, 2)), s.neg[i] ? f2_neg(y) : y, false};
+    }
+    F2 W;
+    gls_table29(tab, W, P);
+    for (int i = top; i >= 0; i--) {
+        jac_dbl(acc, acc);
+        const int w = i >> 5, b = i & 31;
+        const int idx = (int)((s.k[0][w] >> b) & 1) | (int)(((s.k[1][w] >> b) & 1) << 1) | (int)(((s.k[2][w] >> b) & 1) << 2) | (int)(((s.k[3][w] >> b) & 1) << 3);
+        if (idx) {
+            AffP<F2> t;
+            tab_load(tab, idx, t);
+            jac_add_mixed(acc, acc, t);
+        }
+    }
+    if (!acc.inf) acc.z = f2_mul(acc.z, W);
+}
+// field-generic front: G1 takes the two-dimensional GLV loop, G2 the four-dimensional GLS loop
+GPBC_INLINE void scalar_mul29_best(JacP<Fe> &acc, const AffP<Fe> &base, const uint32_t k[8], int32_t *tab) { scalar_mul29_jac<Fe>(acc, base, k, tab); }
+GPBC_INLINE void scalar_mul29_best(JacP<F2> &acc, const AffP<F2> &base, const uint32_t k[8], int32_t *tab) { scalar_mul29_gls(acc, base, k, tab); }
+
 template <class F> GPBC_INLINE void scalar_mul29(AffP<F> &out, const AffP<F> &base, const uint32_t k[8], int32_t *tab) {
     JacP<F> acc;
     scalar_mul29_jac(acc, base, k, tab);

@@ -40,7 +40,7 @@ GPBC_KERNEL k_g2_scalar_mul(const uint8_t *__restrict__ bases, int shared_base, 
         AffP<F2> b = g2_load_aff(bases + (shared_base ? 0 : i * GPBC_G2_BYTES));
         uint32_t k[8];
         load_scalar(k, scalars + i * GPBC_SCALAR_BYTES);
-        scalar_mul29_jac<F2>(res[j], b, k, tabws + t * (size_t)glv_table_dwords<F2>());
+        scalar_mul29_best(res[j], b, k, tabws + t * (size_t)glv_table_dwords<F2>());      // four-dimensional GLS loop
     }
     AffP<F2> aff[SMUL_K];
     jac_to_affine_batch<F2, SMUL_K>(aff, res);
@@ -88,7 +88,7 @@ template <class F> __device__ __forceinline__ void fb_build_lane(const uint8_t *
     uint32_t k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     k[w >> 2] = (uint32_t)d << (8 * (w & 3));
     JacP<F> r;
-    scalar_mul29_jac<F>(r, base, k, tabws + t * (size_t)glv_table_dwords<F>());
+    scalar_mul29_best(r, base, k, tabws + t * (size_t)glv_table_dwords<F>());
     AffP<F> a;
     jac_to_affine(a, r);
     tab_store(table + e * (size_t)TabLayout<F>::ENTRY_DWORDS, 0, a);

@@ -187,3 +187,37 @@ def test_fixed_base_msm_under_bounds(hc):
         for j in range(nbase):
             acc = o.g1_add(acc, o.g1_mul(bases[j], ks[m][j] % o.R) if bases[j] else None)
         assert out[64 * m:64 * m + 64].tobytes() == o.g1_to_bytes(acc), m
+
+
+def test_gls_split_identity_and_size(hc):
+    """gls_split: k = k0 + k1 mu + k2 mu^2 + k3 mu^3 (mod r), mu = 6u^2 (psi's eigenvalue on G2), |k_i| < 2^66, for edge
+    scalars (0, 1, r-1, r, 2^256-1, mu, mu^2 ...) and 20000 random ones; and psi(Q) = [mu]Q in the oracle."""
+    import random
+    random.seed(66)
+    mu = 6 * o.U * o.U % o.R
+    Q = o.g2_mul(o.G2_GEN, 987654321)
+    assert o.g2_frobenius(Q) == o.g2_mul(Q, mu)
+    ks = [0, 1, 2, o.R - 1, o.R, o.R + 1, (1 << 256) - 1, mu, mu - 1, mu * mu % o.R, pow(mu, 3, o.R), o.R // 2, 1 << 255]
+    ks += [random.randrange(1 << 256) for _ in range(20000)]
+    K = np.frombuffer(b"".join(k.to_bytes(32, "little") for k in ks), dtype=np.uint8).copy()
+    out = np.zeros(16 * len(ks), dtype=np.uint32)
+    hc.hc_gls_split(vp(K), ctypes.c_size_t(len(ks)), vp(out))
+    out = out.reshape(len(ks), 4, 4)
+    for t, k in enumerate(ks):
+        acc = 0
+        for i in range(4):
+            mag = int(out[t, i, 0]) | int(out[t, i, 1]) << 32 | int(out[t, i, 2]) << 64
+            assert mag < 1 << 66
+            acc += (-mag if out[t, i, 3] else mag) * pow(mu, i, o.R)
+        assert acc % o.R == k % o.R, k
+
+
+def test_g2_glv_loop_still_agrees(hc):
+    """The two-dimensional GLV loop instantiated for Fp2 (kept for comparison; the G2 kernels use the GLS loop) on the
+    golden scalars."""
+    g = load_golden("g2_scalar_mul.json")["cases"]
+    B, K = cat([c["base"] for c in g]).copy(), cat([c["scalar"] for c in g]).copy()
+    out = np.zeros((len(g), 128), dtype=np.uint8)
+    hc.hc_g2_mul_glv(vp(B), vp(K), ctypes.c_size_t(len(g)), vp(out))
+    for i, c in enumerate(g):
+        assert out[i].tobytes().hex() == c["out"], i

@@ -57,7 +57,7 @@ template <class F, class LoadA, class StoreA> static void smul_batch(const uint8
             if (i >= n) { jac_set_inf(res[j]); continue; }
             uint32_t k[8]; memcpy(k, K + 32 * i, 32);
             alignas(16) int32_t tab[glv_table_dwords<F>()];
-            scalar_mul29_jac<F>(res[j], ld(B + pt * i), k, tab);
+            scalar_mul29_best(res[j], ld(B + pt * i), k, tab);
         }
         AffP<F> aff[KK];
         jac_to_affine_batch<F, KK>(aff, res);
@@ -107,6 +107,27 @@ void hc_glv_split(const uint8_t *K, size_t n, uint32_t *out) {
         GlvSplit s; glv_split(s, k);
         memcpy(out + 12 * i, s.k1, 20); memcpy(out + 12 * i + 5, s.k2, 20);
         out[12 * i + 10] = s.neg1; out[12 * i + 11] = s.neg2;
+    }
+}
+// G2 scalar multiplication by the two-dimensional GLV loop (the G2 kernels use the four-dimensional GLS loop; this keeps the
+// GLV instantiation for F2 under test: the fixed-base table builder may use either)
+void hc_g2_mul_glv(const uint8_t *B, const uint8_t *K, size_t n, uint8_t *out) {
+    for (size_t i = 0; i < n; i++) {
+        uint32_t k[8]; memcpy(k, K + 32 * i, 32);
+        alignas(16) int32_t tab[glv_table_dwords<F2>()];
+        AffP<F2> b{f2_load(B + 128 * i), f2_load(B + 128 * i + 64), bytes_all_zero(B + 128 * i, 32)}, r;
+        JacP<F2> j;
+        scalar_mul29_jac<F2>(j, b, k, tab);
+        jac_to_affine(r, j);
+        f2_store(out + 128 * i, r.x); f2_store(out + 128 * i + 64, r.y);
+    }
+}
+// GLS split of n scalars: out rows = 4 x (3 magnitude words, sign) u32
+void hc_gls_split(const uint8_t *K, size_t n, uint32_t *out) {
+    for (size_t i = 0; i < n; i++) {
+        uint32_t k[8]; memcpy(k, K + 32 * i, 32);
+        GlsSplit s; gls_split(s, k);
+        for (int c = 0; c < 4; c++) { memcpy(out + 16 * i + 4 * c, s.k[c], 12); out[16 * i + 4 * c + 3] = s.neg[c]; }
     }
 }
 void hc_fp_mul(const uint8_t *A, const uint8_t *B, size_t n, uint8_t *out) {

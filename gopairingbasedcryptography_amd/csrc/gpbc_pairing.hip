@@ -325,9 +325,19 @@ int gpbc_set_multi_pair_chunk(int pairs_per_chunk) {
     return GPBC_OK;
 }
 static int multi_pair_core(const uint8_t *dP, const uint8_t *dQ, const uint64_t *seg_off, size_t k, size_t n_pairs, uint8_t *dG, uint8_t *dOk, hipStream_t st) {
-    if (n_pairs < 4 * k && g_multi_chunk.load() <= 0) {
-        // Short segments (BLS checks: 2 pairs; AFP25: 3): sharing squarings among two or three pairs saves ~1 ms per 200 000
-        // pairs, less than the extra chunk-product pass costs; one Miller loop per lane pair and one product per segment.
+    // Chunk length L: as long as possible (more shared squarings) while ~131072 lane pairs stay in flight, and at most
+    // MULTI_CHUNK; with at least 65536 segments that all fit a chunk (AFP25: 3 pairs, BLS checks: 2) a chunk is a whole
+    // segment — the chip is full with one lane pair per segment.  Chunks are launched in groups of MULTI_GROUP = 65536
+    // (131072 lanes = 2048 waves: exactly one full round of two waves per SIMD on 256 CUs — a lane pair here runs for tens
+    // of milliseconds, so a partially filled second round would cost as much as a full one); the slot grid of a group,
+    // L x 65536 lines rows, is at most 10 GB.
+    uint64_t max_len = 0;
+    for (size_t j = 0; j < k; j++) if (seg_off[j + 1] - seg_off[j] > max_len) max_len = seg_off[j + 1] - seg_off[j];
+    uint64_t L = (n_pairs + 131071) / 131072;
+    if (max_len <= (uint64_t)MULTI_CHUNK) L = k >= MULTI_GROUP ? max_len : 1;      // short segments: whole or not at all
+    if (g_multi_chunk.load() > 0) L = (uint64_t)g_multi_chunk.load();
+    if (L <= 1 && g_multi_chunk.load() <= 0) {
+        // nothing to share (few pairs, or single-pair segments): one Miller loop per lane pair and one product per segment
         DevBuf dSeg, dW;
         TRY(dSeg.upload(seg_off, (k + 1) * sizeof(uint64_t)));
         const size_t wsb = gpbc_multi_pair_workspace_bytes(n_pairs, k);
@@ -340,12 +350,6 @@ static int multi_pair_core(const uint8_t *dP, const uint8_t *dQ, const uint64_t 
         HIP_TRY(hipStreamSynchronize(st));
         return GPBC_OK;
     }
-    // Chunk length L: as long as possible (more shared squarings) while ~131072 lane pairs stay in flight, and at most
-    // MULTI_CHUNK.  Chunks are launched in groups of MULTI_GROUP = 65536 (131072 lanes = 2048 waves: exactly one full round
-    // of two waves per SIMD on 256 CUs — a lane pair here runs for tens of milliseconds, so a partially filled second round
-    // would cost as much as a full one); the slot grid of a group, L x 65536 lines rows, is at most 10 GB.
-    uint64_t L = (n_pairs + 131071) / 131072;
-    if (g_multi_chunk.load() > 0) L = (uint64_t)g_multi_chunk.load();
     if (L < 1) L = 1;
     if (L > (uint64_t)MULTI_CHUNK) L = MULTI_CHUNK;
     std::vector<uint64_t> chunk_off(1, 0), seg_chunk(1, 0);
@@ -363,9 +367,9 @@ static int multi_pair_core(const uint8_t *dP, const uint8_t *dQ, const uint64_t 
         std::lock_guard<std::mutex> seq(g_ws_seq_mu);
         for (size_t cb = 0; cb < n_chunks; cb += MULTI_GROUP) {
             const size_t g = n_chunks - cb < MULTI_GROUP ? n_chunks - cb : MULTI_GROUP;
-            size_t max_len = 0;
-            for (size_t c = cb; c < cb + g; c++) { size_t len = (size_t)(chunk_off[c + 1] - chunk_off[c]); if (len > max_len) max_len = len; }
-            const size_t n_slots = max_len * g;
+            size_t longest = 0;
+            for (size_t c = cb; c < cb + g; c++) { size_t len = (size_t)(chunk_off[c + 1] - chunk_off[c]); if (len > longest) longest = len; }
+            const size_t n_slots = longest * g;
             int32_t *lines = nullptr;
             TRY(lines_workspace(st, n_slots, &lines));
             const uint64_t *co = (const uint64_t *)dChunkOff.p + cb;

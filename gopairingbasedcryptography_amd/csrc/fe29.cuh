@@ -301,6 +301,58 @@ GPBC_INLINE void fe_mul_dual(Fe &r0, Fe &r1, const Fe &a0, const Fe &b0, const F
 #endif
 }
 
+// The two halves of an F2 squaring, lazily and without forming a0 +- a1:  r0 = (a0^2 - a1^2)/R' from the symmetric halves of
+// the two squares (45 + 45 product MADs, one reduction), r1 = (2 a0 a1)/R' (81 + reduction) — 333 MADs against 324 for the
+// (a0+a1)(a0-a1) form, but no operand sums to normalise (~70 instructions fewer per squaring).  Operands normalised.
+GPBC_INLINE void fe_sqrdiff_mul_dual(Fe &r0, Fe &r1, const Fe &a0, const Fe &a1) {
+#ifdef GPBC_BOUNDS
+    r0 = fe_mul_core<true>(a0, a0, fe_neg(a1), a1);
+    r1 = fe_mul_core<false>(fe_dbl(a0), a1, a0, a1);
+#else
+    int32_t d0[NL], n1[NL], dn1[NL], m0[NL], m1[NL];
+#pragma unroll
+    for (int i = 0; i < NL; i++) { d0[i] = a0.v[i] * 2; n1[i] = -a1.v[i]; dn1[i] = -2 * a1.v[i]; }
+    int64_t acc0 = 0, acc1 = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * NL - 1; k++) {
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            const int j = k - i;
+            if (j < 0 || j >= NL) continue;
+            acc1 += (int64_t)d0[i] * (int64_t)a1.v[j];
+            if (i > j) continue;
+            if (i == j) {
+                acc0 += (int64_t)a0.v[i] * (int64_t)a0.v[i];
+                acc0 += (int64_t)n1[i] * (int64_t)a1.v[i];
+            } else {
+                acc0 += (int64_t)d0[i] * (int64_t)a0.v[j];
+                acc0 += (int64_t)dn1[i] * (int64_t)a1.v[j];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            const int j = k - i;
+            if (j < 1 || j >= NL) continue;
+            acc0 += (int64_t)m0[i] * (int64_t)f29_p(j);
+            acc1 += (int64_t)m1[i] * (int64_t)f29_p(j);
+        }
+        if (k < NL) {
+            m0[k] = (int32_t)(((uint32_t)acc0 * (uint32_t)F29_PINV) & (uint32_t)LMASK);
+            m1[k] = (int32_t)(((uint32_t)acc1 * (uint32_t)F29_PINV) & (uint32_t)LMASK);
+            acc0 += (int64_t)m0[k] * (int64_t)f29_p(0);
+            acc1 += (int64_t)m1[k] * (int64_t)f29_p(0);
+        } else {
+            r0.v[k - NL] = (int32_t)(acc0 & LMASK);
+            r1.v[k - NL] = (int32_t)(acc1 & LMASK);
+        }
+        acc0 >>= LB;
+        acc1 >>= LB;
+    }
+    r0.v[NL - 1] = (int32_t)acc0;
+    r1.v[NL - 1] = (int32_t)acc1;
+#endif
+}
+
 #define GPBC_ARGS9(x) int32_t x##0, int32_t x##1, int32_t x##2, int32_t x##3, int32_t x##4, int32_t x##5, int32_t x##6, int32_t x##7, int32_t x##8
 #define GPBC_PASS9(x) x.v[0], x.v[1], x.v[2], x.v[3], x.v[4], x.v[5], x.v[6], x.v[7], x.v[8]
 #define GPBC_PACK9(x) Fe{{x##0, x##1, x##2, x##3, x##4, x##5, x##6, x##7, x##8}}

@@ -38,7 +38,7 @@ template <bool NORM> GPBC_INLINE F2 f2_mul_core(const F2 &xx, const F2 &yy) {
 template <bool NORM> GPBC_INLINE F2 f2_sqr_core(const F2 &xx) {
     F2 x = NORM ? f2_norm(xx) : xx;
     F2 r;
-    fe_mul_dual(r.a0, r.a1, fe_norm(fe_add(x.a0, x.a1)), fe_norm(fe_sub(x.a0, x.a1)), fe_dbl(x.a0), x.a1);
+    fe_sqrdiff_mul_dual(r.a0, r.a1, x.a0, x.a1);          // (a0^2 - a1^2, 2 a0 a1) without the operand sums
     return r;
 }
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(GPBC_BOUNDS) && !defined(GPBC_INLINE_LEAVES)

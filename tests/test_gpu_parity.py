@@ -622,3 +622,25 @@ def test_hash_to_curve_large_batch_properties(eng):
     assert ok.all()
     Qbad = np.stack([np.roll(H2[:m], 1, axis=0), negY.reshape(m, 128)], axis=1).reshape(-1)
     assert not eng.pairing_check_batch(P, Qbad, np.arange(0, 2 * m + 1, 2)).any()
+
+
+def test_tiny_and_empty_batches(eng, oracle):
+    """n = 1 and n = 0 through the newer entry points (grids of one partially filled wave; empty inputs are no-ops)."""
+    import torch
+    g1, g2 = eng.generators()
+    k = scalars("tiny", 2)
+    P = eng.g1_scalar_mul(g1, k[:32])
+    Q = eng.g2_scalar_mul(g2, k[32:])
+    want = oracle.pair_batch(P, Q, threads=1)
+    assert (eng.multi_pair_fixed_q(P, Q) == want).all()
+    assert (eng.multi_pair(torch.from_numpy(P).cuda(), torch.from_numpy(Q).cuda(), np.array([0, 1], dtype=np.uint64)).cpu().numpy() == want).all()
+    fb = eng.FixedBase(P)
+    assert (fb.mul(k[32:]) == oracle.g1_scalar_mul(P, k[32:], threads=1)).all()
+    back, ok = eng.g2_unmarshal(eng.g2_marshal(Q, compressed=True), elem_bytes=64)
+    assert ok.tolist() == [1] and (back == Q).all()
+    assert eng.map_to_g1(np.zeros(64, dtype=np.uint8)).shape == (1, 64)
+    assert (eng.gt_exp(want, [5]) == oracle.gt_exp(want, np.frombuffer((5).to_bytes(32, "little"), dtype=np.uint8))).all()
+    empty = np.zeros(0, dtype=np.uint8)
+    assert eng.g1_marshal(empty).shape == (0, 64) and eng.g2_unmarshal(empty)[0].shape == (0, 128)
+    assert eng.map_to_g2(empty).shape == (0, 128) and eng.gt_marshal(empty).shape == (0, 384)
+    assert eng.g1_scalar_mul(empty, empty).shape[0] == 0

@@ -475,9 +475,16 @@ GPBC_INLINE Fe fe_halve(const Fe &a) {
     return r;
 }
 
-// Value reduction without a multiplication: subtract k*p with k = round(top limb / p_8).  Input: weakly normalised,
+// Value reduction without a multiplication: subtract the table row k*p with k = round(top limb / p_8).  Input: weakly normalised,
 // |value| < 256p.  Output: |value| < 0.51p, limbs 0..7 within +-(2^29 + 2^9).  Used where a small-constant multiple
 // (the non-residue 9+i) would otherwise let the worst-case magnitude compound through the tower.
+// k * p for k in [-256, 256] (row k + 256): limbs 0..7 in [0, 2^29), top limb signed (tools/gen_constants.py).  21 KB,
+// resident in the caches: k is almost always within a few units of zero.
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ const int32_t F29_KP[513][12] = F29_KP_ROWS;
+#else
+static const int32_t F29_KP[513][12] = F29_KP_ROWS;
+#endif
 GPBC_INLINE Fe fe_reduce(const Fe &a) {
 #ifdef GPBC_BOUNDS
     if (a.vb >= 256.0) bounds_fail("fe_reduce input value", a.vb, 256.0);
@@ -485,17 +492,13 @@ GPBC_INLINE Fe fe_reduce(const Fe &a) {
 #endif
     constexpr int32_t P8 = f29_p(NL - 1);
     int32_t k = (int32_t)rintf((float)a.v[NL - 1] * (1.0f / (float)P8));
+    k = k < -256 ? -256 : (k > 256 ? 256 : k);          // never taken for in-bound inputs; keeps the row index in the table
+    const int32_t *row = F29_KP[k + 256];
     Fe r;
-    int32_t hi_prev = 0;
 #pragma unroll
-    for (int i = 0; i < NL; i++) {
-        int64_t t = (int64_t)k * (int64_t)f29_p(i);
-        int32_t lo = (int32_t)(t & LMASK), hi = (int32_t)(t >> LB);
-        r.v[i] = (i < NL - 1) ? a.v[i] - lo - hi_prev : a.v[i] - (int32_t)t - hi_prev;
-        hi_prev = hi;
-    }
+    for (int i = 0; i < NL; i++) r.v[i] = a.v[i] - row[i];
 #ifdef GPBC_BOUNDS
-    for (int i = 0; i < NL - 1; i++) r.lb[i] = a.lb[i] + 257;       // lo in [0,2^29) never adds magnitude beyond the input's; hi within +-256
+    for (int i = 0; i < NL - 1; i++) r.lb[i] = a.lb[i] + 257;       // a row limb lies in [0, 2^29): it never adds magnitude beyond the input's
     for (int i = 0; i < NL - 1; i++) if (r.lb[i] < 536870912.0 + 257) r.lb[i] = 536870912.0 + 257;
     r.lb[NL - 1] = (double)P8 / 2 + 270;
     r.vb = 0.51;

@@ -508,6 +508,36 @@ GPBC_INLINE Fe fe_reduce(const Fe &a) {
     return r;
 }
 
+// The same reduction with k*p formed arithmetically (nine 64-bit multiplies with splits, no memory access): used by the
+// Miller accumulator, whose memory pipeline is busy streaming the lines — there the table loads cost more than they save
+// (measured: k_miller_accumulate 14.6 -> 15.1 ms with the table, k_final_exp 77.6 -> 76.0 ms).
+GPBC_INLINE Fe fe_reduce_arith(const Fe &a) {
+#ifdef GPBC_BOUNDS
+    if (a.vb >= 256.0) bounds_fail("fe_reduce input value", a.vb, 256.0);
+    for (int i = 0; i < NL - 1; i++) if (a.lb[i] > 536870912.0 + 1024) bounds_fail("fe_reduce input limb (normalise first)", a.lb[i], 536870912.0 + 1024);
+#endif
+    constexpr int32_t P8 = f29_p(NL - 1);
+    int32_t k = (int32_t)rintf((float)a.v[NL - 1] * (1.0f / (float)P8));
+    Fe r;
+    int32_t hi_prev = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        int64_t t = (int64_t)k * (int64_t)f29_p(i);
+        int32_t lo = (int32_t)(t & LMASK), hi = (int32_t)(t >> LB);
+        r.v[i] = (i < NL - 1) ? a.v[i] - lo - hi_prev : a.v[i] - (int32_t)t - hi_prev;
+        hi_prev = hi;
+    }
+#ifdef GPBC_BOUNDS
+    for (int i = 0; i < NL - 1; i++) r.lb[i] = a.lb[i] + 257;       // lo in [0,2^29) never adds magnitude beyond the input's; hi within +-256
+    for (int i = 0; i < NL - 1; i++) if (r.lb[i] < 536870912.0 + 257) r.lb[i] = 536870912.0 + 257;
+    r.lb[NL - 1] = (double)P8 / 2 + 270;
+    r.vb = 0.51;
+    bound_stats().reduces++;
+    check_limbs(r, "fe_reduce limb");
+#endif
+    return r;
+}
+
 // ------------------------------------------------------------------------------------------------ canonical form, I/O
 // Fully reduce to [0,p) with limbs in [0,2^29) (limb 8 < 2^24). Input value must lie in (-4p, 4p).
 GPBC_INLINE Fe fe_canonical(const Fe &a) {

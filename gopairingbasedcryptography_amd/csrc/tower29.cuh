@@ -111,6 +111,8 @@ GPBC_INLINE F6 f6_sub(const F6 &x, const F6 &y) { return F6{f2_sub(x.b0, y.b0), 
 GPBC_INLINE F6 f6_neg(const F6 &x) { return F6{f2_neg(x.b0), f2_neg(x.b1), f2_neg(x.b2)}; }
 GPBC_INLINE F6 f6_norm(const F6 &x) { return F6{f2_norm(x.b0), f2_norm(x.b1), f2_norm(x.b2)}; }
 GPBC_INLINE F6 f6_reduce(const F6 &x) { return F6{f2_reduce(x.b0), f2_reduce(x.b1), f2_reduce(x.b2)}; }
+GPBC_INLINE F2 f2_reduce_arith(const F2 &x) { return F2{fe_reduce_arith(x.a0), fe_reduce_arith(x.a1)}; }
+GPBC_INLINE F6 f6_reduce_arith(const F6 &x) { return F6{f2_reduce_arith(x.b0), f2_reduce_arith(x.b1), f2_reduce_arith(x.b2)}; }
 // x * v: (xi b2, b0, b1); N-class in and out
 template <bool RX> GPBC_INLINE F6 f6_mul_v_t(const F6 &x) { return F6{f2_mul_xi_t<RX>(x.b2), x.b0, x.b1}; }
 GPBC_INLINE F6 f6_mul_v(const F6 &x) { return f6_mul_v_t<true>(x); }

@@ -79,7 +79,8 @@ template <class X> GPBC_INLINE F6 f12p_mul_034(const X &x, const F6 &h, const F2
     F6 r1 = f6_mul_01_t<false>(h, c3, c4, s34);
     F6 p1 = x.swap(r1);
     F6 add = f6_sel(x.odd, p1, f6_mul_v_t<false>(p1));
-    return f6_reduce(f6_norm(f6_add(r0, add)));                          // the one value reduction of this step
+    return f6_reduce_arith(f6_norm(f6_add(r0, add)));                    // the one value reduction of this step (no table loads
+                                                                         // here: this runs beside the lines stream, see fe29.cuh)
 }
 
 // full product (Karatsuba over F6).  The third product (a0+a1)(b0+b1) is itself split: the even lane computes its three

@@ -2,7 +2,8 @@
 // 29-bit-limb field, one point per lane.  Replaces gnark-crypto's G1Affine/G2Affine.ScalarMultiplication(Base) as
 // called at signature/bls01_signature/bls_signature.go:45,63, cpabe/bsw07/bsw07_cpabe.go:69-160,
 // bibe/afp25_bibe/afp25_bibe_utils.go:48,51.  The affine result is canonical, so the algorithm is free
-// (gnark: GLV + Jacobian); here: Jacobian coordinates, a = 0 doubling, mixed addition, left-to-right binary.
+// (gnark: GLV + Jacobian); here: Jacobian coordinates, a = 0 doubling, mixed addition, endomorphism splits (GLV for G1,
+// four-dimensional GLS for G2) with fixed joint windows over a common-Z table, safegcd inversion for the affine result.
 #ifndef GPBC_CURVE29_CUH
 #define GPBC_CURVE29_CUH
 #include "tower29.cuh"

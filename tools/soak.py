@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Randomised soak of the GPU engine against the C restatement (oracle/): many more inputs than the test-suite uses, to
+reach rare paths (exact zero tests, exceptional additions, large table indices).  Test infrastructure — run on a GPU box:
+    python tools/soak.py [n]        (default n = 65536)
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import oracle_lib  # noqa: E402
+from gopairingbasedcryptography_amd import bn254  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+threads = min(os.cpu_count() or 1, 16)
+oracle_lib.build()
+bn254.init(0)
+rng = np.random.default_rng(20261004)
+
+
+def scal(m, full=False):
+    a = rng.integers(0, 256, size=(m, 32), dtype=np.uint8)
+    if not full:
+        a[:, 31] &= 0x1f
+    a[: min(m, 8)] = 0
+    a[0, 0], a[1, 0], a[2, 0] = 1, 2, 3                       # tiny scalars among the first rows; row 3.. stay zero
+    return a.reshape(-1)
+
+
+g1, g2 = bn254.generators()
+t0 = time.time()
+P = bn254.g1_scalar_mul(g1, scal(n))                          # fixed-base path (n >= 16384)
+Q = bn254.g2_scalar_mul(g2, scal(n))
+k1, k2 = scal(n, full=True), scal(n, full=True)
+R1 = bn254.g1_scalar_mul(P, k1)                               # variable base, 256-bit scalars
+R2 = bn254.g2_scalar_mul(Q, k2)
+assert (R1 == oracle_lib.g1_scalar_mul(P, k1, threads=threads)).all(), "G1 scalar mul"
+assert (R2 == oracle_lib.g2_scalar_mul(Q, k2, threads=threads)).all(), "G2 scalar mul"
+print("scalar multiplications ok  (%d each, %.1f s)" % (n, time.time() - t0), flush=True)
+t0 = time.time()
+gt = bn254.pair_batch(P, Q)
+assert (gt == oracle_lib.pair_batch(P, Q, threads=threads)).all(), "pairing"
+print("pairings ok  (%d, %.1f s)" % (n, time.time() - t0), flush=True)
+t0 = time.time()
+lens = rng.integers(0, 12, size=n // 4)
+off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+m = int(off[-1])
+idx = rng.integers(0, n, size=m)
+Pm, Qm = P[idx], Q[idx]
+assert (bn254.multi_pair(Pm, Qm, off) == oracle_lib.multi_pair(Pm, Qm, off, threads=threads)).all(), "multi-pairing"
+print("multi-pairings ok  (%d segments, %d pairs, %.1f s)" % (len(lens), m, time.time() - t0), flush=True)
+t0 = time.time()
+ke = scal(4096, full=True)
+assert (bn254.gt_exp(gt[:4096], ke) == oracle_lib.gt_exp(gt[:4096], ke, threads=threads)).all(), "GT exp"
+assert (bn254.gt_mul(gt[:4096], gt[4096:8192]) == oracle_lib.gt_mul(gt[:4096], gt[4096:8192])).all(), "GT mul"
+fb = bn254.FixedBase(P[:16])
+ks = scal(16 * 512, full=True)
+want = np.stack([np.asarray(oracle_lib.g1_sum(oracle_lib.g1_scalar_mul(P[:16], ks.reshape(512, -1)[i], threads=threads))).reshape(-1) for i in range(512)])
+assert (fb.msm(ks) == want).all(), "fixed-base MSM"
+back, ok = bn254.g2_unmarshal(bn254.g2_marshal(R2, compressed=True), elem_bytes=64)
+assert ok.all() and (back == R2).all(), "G2 wire round trip"
+back, ok = bn254.g1_unmarshal(bn254.g1_marshal(R1, compressed=True), elem_bytes=32)
+assert ok.all() and (back == R1).all(), "G1 wire round trip"
+print("GT ops, fixed-base MSM, wire round trips ok  (%.1f s)" % (time.time() - t0), flush=True)
+print("soak OK")

@@ -155,6 +155,33 @@ inline std::vector<G2Affine> G2ScalarMultiplicationBatch(const std::vector<G2Aff
     check(gpbc_g2_scalar_mul_batch(bases.data(), bases.size(), s.data(), s.size(), out.data()));
     return out;
 }
+// k products against ONE list of G2 points (a decryption key against k ciphertexts): out[j] = Pair(P[j*m .. (j+1)*m), Q);
+// the Miller lines of Q are computed once (gnark: PrecomputeLines / MillerLoopFixedQ)
+inline std::vector<GT> PairFixedQ(const std::vector<G1Affine> &P, const std::vector<G2Affine> &Q) {
+    if (Q.empty() || P.empty() || P.size() % Q.size()) throw std::invalid_argument("invalid inputs sizes");
+    std::vector<GT> out(P.size() / Q.size());
+    check(gpbc_multi_pair_fixed_q(P.data(), Q.data(), Q.size(), out.size(), out.data()));
+    return out;
+}
+// Fixed-base window tables in HBM: ScalarMultiplicationBase-style batches and sums  sum_j [s_j] base_j  over fixed bases
+class G1FixedBase {
+public:
+    explicit G1FixedBase(const std::vector<G1Affine> &bases) : n_(bases.size()) { check(gpbc_g1_fixed_base_create(bases.data(), bases.size(), &h_)); }
+    ~G1FixedBase() { gpbc_fixed_base_destroy(h_); }
+    G1FixedBase(const G1FixedBase &) = delete;
+    G1FixedBase &operator=(const G1FixedBase &) = delete;
+    // scalars: n_msm rows of NBases() scalars; one point per row
+    std::vector<G1Affine> Msm(const std::vector<Scalar> &scalars) const {
+        if (scalars.size() % n_) throw std::invalid_argument("need one scalar per base and sum");
+        std::vector<G1Affine> out(scalars.size() / n_);
+        check(gpbc_fixed_base_msm(h_, scalars.data(), out.size(), out.data()));
+        return out;
+    }
+    size_t NBases() const { return n_; }
+private:
+    gpbc_fixed_base *h_ = nullptr;
+    size_t n_;
+};
 static_assert(sizeof(Scalar) == GPBC_SCALAR_BYTES, "scalar layout");
 
 }  // namespace bn254

@@ -75,6 +75,21 @@ int main() {
         try { back.Unmarshal(bad); } catch (const std::invalid_argument &) { rejected = true; }
         EXPECT(rejected);
     }
+    // fixed-Q multi-pairing and fixed-base tables through the mirror
+    {
+        std::vector<G1Affine> Ps = {a.pk, g1, b.pk, g1};               // two segments of two points against {hm, -sigma}
+        G2Affine hm = HashStandIn("hello pairing"), inv; inv.Neg(sig);
+        std::vector<GT> fq = PairFixedQ(Ps, {hm, inv});
+        GT one; one.Div(e, e);
+        EXPECT(fq.size() == 2 && fq[0].Equal(one) && !fq[1].Equal(one));   // a's signature verifies, b's key does not
+        EXPECT(fq[0].Equal(Pair({a.pk, g1}, {hm, inv})) && fq[1].Equal(Pair({b.pk, g1}, {hm, inv})));
+        G1FixedBase fb({g1, a.pk});
+        std::vector<G1Affine> s = fb.Msm({Scalar(5), Scalar(7), Scalar(0), Scalar(1)});
+        G1Affine t5, t7, want;
+        t5.ScalarMultiplication(g1, Scalar(5)); t7.ScalarMultiplication(a.pk, Scalar(7));
+        check(gpbc_g1_sum(std::vector<G1Affine>{t5, t7}.data(), 2, &want));
+        EXPECT(s.size() == 2 && s[0].Equal(want) && s[1].Equal(a.pk));
+    }
     printf("BLS flow OK\n");
     return 0;
 }

@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(BLOCK) k_gt_is_one(const uint8_t *__restrict__
 }
 
 // GT.Exp: left-to-right square-and-multiply on a 256-bit plain exponent (k = 0 -> one)
-GPBC_KERNEL k_gt_exp(const uint8_t *__restrict__ x, const uint8_t *__restrict__ kk, uint8_t *__restrict__ out, size_t n) {
+GPBC_KERNEL k_gt_exp(const uint8_t *__restrict__ x, const uint8_t *__restrict__ kk, uint8_t *__restrict__ out, size_t n, int32_t *__restrict__ tabws) {
     size_t lane = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     size_t i = lane >> 1;                                   // one Fp12 per lane pair
     if (i >= n) return;
@@ -193,7 +193,7 @@ GPBC_KERNEL k_gt_exp(const uint8_t *__restrict__ x, const uint8_t *__restrict__ 
     size_t off = i * GPBC_GT_BYTES + (px.odd ? 192 : 0);
     uint32_t k[8];
     load_scalar(k, kk + i * GPBC_SCALAR_BYTES);
-    f6_store(out + off, f12p_exp256(px, f6_load(x + off), k));
+    f6_store(out + off, f12p_exp256(px, f6_load(x + off), k, tabws + lane * (size_t)GT_EXP_TAB_DWORDS));
 }
 
 // op 0: a*b   1: a*b^-1   2: a^-1
@@ -259,8 +259,19 @@ int gpbc_gt_exp_batch_dev(const void *d_x, const void *d_k, size_t n, void *d_ou
     if (!n) return GPBC_OK;
     if (!d_x || !d_k || !d_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
     TRY(bind_device());
-    k_gt_exp<<<grid_for(2 * n), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_x, (const uint8_t *)d_k, (uint8_t *)d_out, n);
-    return check_launch("k_gt_exp");
+    hipStream_t st = (hipStream_t)stream;
+    constexpr size_t CHUNK = 131072;                       // elements per launch: 1 GB of window tables (4 KB per lane)
+    const size_t chunk = n < CHUNK ? n : CHUNK;
+    std::lock_guard<std::mutex> seq(g_ws_seq_mu);
+    int32_t *tabws = nullptr;
+    TRY(stream_workspace(st, 2 * chunk * GT_EXP_TAB_DWORDS * sizeof(int32_t), &tabws));
+    for (size_t off = 0; off < n; off += chunk) {
+        const size_t m = n - off < chunk ? n - off : chunk;
+        k_gt_exp<<<grid_for(2 * m), BLOCK, 0, st>>>((const uint8_t *)d_x + off * GPBC_GT_BYTES, (const uint8_t *)d_k + off * GPBC_SCALAR_BYTES,
+                                                    (uint8_t *)d_out + off * GPBC_GT_BYTES, m, tabws);
+        TRY(check_launch("k_gt_exp"));
+    }
+    return GPBC_OK;
 }
 static int gt_binary_dev(int op, const void *a, const void *b, size_t n, void *out, void *stream) {
     if (!n) return GPBC_OK;

@@ -116,17 +116,48 @@ template <class X> GPBC_INLINE F6 final_exp_pair(const X &x, const F6 &in) {
 }
 
 // b^k for a 256-bit k (GT.Exp: generic squarings, so any Fp12 element is handled, not only the cyclotomic subgroup;
-// no reduction of k): fixed 4-bit windows, left to right, table b^0..b^15 in private memory.
-template <class X> GPBC_NOINLINE F6 f12p_exp256(const X &x, const F6 &b, const uint32_t (&k)[8]) {
-    F6 tab[16];
-    tab[0] = f12p_one(x);
-    tab[1] = b;
-    for (int i = 2; i < 16; i++) tab[i] = f12p_mul(x, tab[i - 1], b);
-    F6 r = tab[(k[7] >> 28) & 15];
+// no reduction of k): fixed 4-bit windows, left to right.  The table b^0..b^15 (this lane's half of each power) lives in a
+// caller-provided block of GT_EXP_TAB_DWORDS int32, one contiguous 256-byte row per entry — not in a private array, whose
+// dword-swizzled layout would make every one of the 54 dwords of a per-lane-indexed entry a separate cache line.
+constexpr int GT_EXP_ROW_DWORDS = 64, GT_EXP_TAB_DWORDS = 16 * GT_EXP_ROW_DWORDS;
+GPBC_INLINE void f6_row_store(int32_t *row, const F6 &v) {
+    const Fe *fe[6] = {&v.b0.a0, &v.b0.a1, &v.b1.a0, &v.b1.a1, &v.b2.a0, &v.b2.a1};
+    int32_t w[56];
+#pragma unroll
+    for (int e = 0; e < 6; e++)
+#pragma unroll
+        for (int i = 0; i < NL; i++) w[e * NL + i] = fe[e]->v[i];
+    w[54] = 0; w[55] = 0;
+    TabQuad *q = reinterpret_cast<TabQuad *>(row);
+#pragma unroll
+    for (int j = 0; j < 14; j++) q[j] = TabQuad{w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]};
+}
+GPBC_INLINE F6 f6_row_load(const int32_t *row) {
+    const TabQuad *q = reinterpret_cast<const TabQuad *>(row);
+    int32_t w[56];
+#pragma unroll
+    for (int j = 0; j < 14; j++) { TabQuad t = q[j]; w[4 * j] = t.a; w[4 * j + 1] = t.b; w[4 * j + 2] = t.c; w[4 * j + 3] = t.d; }
+    F6 v;
+    Fe *fe[6] = {&v.b0.a0, &v.b0.a1, &v.b1.a0, &v.b1.a1, &v.b2.a0, &v.b2.a1};
+#pragma unroll
+    for (int e = 0; e < 6; e++) {
+#pragma unroll
+        for (int i = 0; i < NL; i++) fe[e]->v[i] = w[e * NL + i];
+        GPBC_B(set_class_n(*fe[e], 1.5);)          // table entries are outputs of f12p_mul (value-reduced, normalised)
+    }
+    return v;
+}
+template <class X> GPBC_NOINLINE F6 f12p_exp256(const X &x, const F6 &b, const uint32_t (&k)[8], int32_t *tab) {
+    F6 cur = f12p_one(x);
+    f6_row_store(tab, cur);
+    cur = b;
+    f6_row_store(tab + GT_EXP_ROW_DWORDS, cur);
+    for (int i = 2; i < 16; i++) { cur = f12p_mul(x, cur, b); f6_row_store(tab + i * GT_EXP_ROW_DWORDS, cur); }
+    F6 r = f6_row_load(tab + ((k[7] >> 28) & 15) * GT_EXP_ROW_DWORDS);
     for (int w = 62; w >= 0; w--) {
         for (int s = 0; s < 4; s++) r = f6_reduce(f12p_sqr(x, r));
         int d = (k[w >> 3] >> (4 * (w & 7))) & 15;
-        r = f12p_mul(x, r, tab[d]);                         // d = 0 multiplies by one: no divergence inside the pair or the wave
+        r = f12p_mul(x, r, f6_row_load(tab + d * GT_EXP_ROW_DWORDS));      // d = 0 multiplies by one: no divergence
     }
     return r;
 }

@@ -221,7 +221,8 @@ void hc_gt_exp_pair(const uint8_t *A, const uint8_t *K, size_t n, uint8_t *out) 
         auto lane = [&](bool odd) {
             PairHost x{odd, &rv};
             size_t o = 384 * i + (odd ? 192 : 0);
-            f6_store(out + o, f12p_exp256(x, f6_load(A + o), k));
+            alignas(16) int32_t tab[GT_EXP_TAB_DWORDS];
+            f6_store(out + o, f12p_exp256(x, f6_load(A + o), k, tab));
             stats_flush();
         };
         std::thread t1(lane, true);

@@ -69,11 +69,20 @@ def commit_g1_many(table, coeff_rows):
     return np.asarray(table.msm(rows))
 
 
-def decrypt_batch(engine, g1, tau_powers, D, f_coeffs, sk, items, table=None):
+def decrypt_batch(engine, g1, tau_powers, D, f_coeffs, sk, items, table=None, identities=None):
     """items: list of (identity, C1 [3,128], C2 [384]) all encrypted under the batch digest D and key sk.
+    identities: the batch's identity list (what Digest was computed from); when given, the reference's error behaviour for
+    absent and for duplicated identities is reproduced (a duplicated identity is still a root of f, so the quotient alone
+    would not notice it).
     Returns the messages [n,384]: m_i = C2_i / (e(D, C1_i[0]) e(pi_i, C1_i[1]) e(sk, C1_i[2])).
     With `table` (srs_table) all opening proofs pi_i come from one fixed-base MSM call instead of one scalar-multiplication
     batch and one point sum per item."""
+    if identities is not None:
+        # the reference's Decrypt removes every identity equal to id from the batch list and fails unless exactly one was
+        # removed (bibe/afp25_bibe/afp25_bibe.go:371-381): an identity that is absent OR duplicated in the batch is an error
+        for ident, _, _ in items:
+            if sum(1 for x in identities if x % R_ORDER == ident % R_ORDER) != 1:
+                raise ValueError("identity not found in identity list")
     if table is not None:
         pis = commit_g1_many(table, [quotient_by_root(f_coeffs, ident) for ident, _, _ in items])
     else:

@@ -35,20 +35,42 @@ _G2_GEN_HEX = (
     "862fa052fc50e9096b7bea3a83f0fe14f6e96b889dfa9d61789b9ef597d27ffefe7d1b23621a9eff06429eaeeb7efd28"
     "ee5618c7565b0964bb3c7d3222f957dc76103533be35f9558264fd93e6a0a40d")
 
-_initialised_device = None
+_slots = None          # HIP ordinal -> slot index of the bound device list (None before init)
 
 
 def init(device=0):
-    """Bind the process to one HIP device (one process per GPU)."""
-    global _initialised_device
+    """Bind the process to one HIP device (one process per GPU: `init(local_rank)`) or to a list of them (one process
+    driving several GPUs: host-pointer batch calls then shard over all of them; CUDA tensors pick their own device)."""
+    global _slots
     lib = _lib.load()
-    _lib.check(lib.gpbc_init(ctypes.c_int(device)))
-    _initialised_device = device
+    devs = [int(device)] if isinstance(device, int) else [int(d) for d in device]
+    arr = (ctypes.c_int * len(devs))(*devs)
+    _lib.check(lib.gpbc_init_devices(arr, ctypes.c_int(len(devs))))
+    _slots = {}
+    for i, d in enumerate(devs):
+        _slots.setdefault(d, i)
     return device
 
 
+def init_all():
+    """Bind every visible device; returns their number."""
+    n = _lib.check(_lib.load().gpbc_device_count())
+    init(list(range(n)))
+    return n
+
+
+def num_devices():
+    return int(_lib.load().gpbc_num_devices())
+
+
+def shutdown():
+    global _slots
+    _lib.check(_lib.load().gpbc_shutdown())
+    _slots = None
+
+
 def _ensure_init():
-    if _initialised_device is None:
+    if _slots is None:
         init(0)
 
 
@@ -98,6 +120,27 @@ def _tptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+def _tchk(first, *specs):
+    """Validate the HBM-resident arguments of one call before their raw pointers cross the C ABI: every (tensor, bytes,
+    name) must be a contiguous uint8 CUDA tensor of exactly `bytes` bytes on the device of `first`; that device must be one
+    of the bound ones and becomes the calling thread's current device.  A wrong size here would be an out-of-bounds device
+    access inside a kernel, so it is a ValueError on the host instead."""
+    dev = first.device
+    for t, nbytes, name in specs:
+        if not _is_torch(t) or t.dtype.__str__() != "torch.uint8" or not t.is_contiguous():
+            raise ValueError("%s must be a contiguous uint8 CUDA tensor" % name)
+        if t.numel() != nbytes:
+            raise ValueError("%s holds %d bytes, expected %d" % (name, t.numel(), nbytes))
+        if t.device != dev:
+            raise ValueError("%s is on %s, expected %s" % (name, t.device, dev))
+    if not first.is_cuda:
+        raise ValueError("device buffers must be CUDA tensors (host data goes in as numpy arrays)")
+    idx = dev.index if dev.index is not None else 0
+    if _slots is None or idx not in _slots:
+        raise ValueError("device %s is not bound: call bn254.init() with it" % dev)
+    _lib.check(_lib.load().gpbc_set_device(ctypes.c_int(_slots[idx])))
+
+
 def _tnew(like, n, width):
     import torch
     return torch.empty((n, width), dtype=torch.uint8, device=like.device)
@@ -110,9 +153,10 @@ def pair_batch(P, Q, out=None):
     lib = _lib.load()
     if _is_torch(P):
         n = P.numel() // G1_BYTES
-        if Q.numel() // G2_BYTES != n or n == 0:
+        if not _is_torch(Q) or Q.numel() // G2_BYTES != n or n == 0:
             raise ValueError("invalid inputs sizes")
         out = _tnew(P, n, GT_BYTES) if out is None else out
+        _tchk(P, (P, n * G1_BYTES, "P"), (Q, n * G2_BYTES, "Q"), (out, n * GT_BYTES, "out"))
         _lib.check(lib.gpbc_pair_batch_dev(_tptr(P), _tptr(Q), _sz(n), _tptr(out), _torch_stream()))
         return out
     P, Q = _np(P, G1_BYTES), _np(Q, G2_BYTES)
@@ -131,7 +175,7 @@ def multi_pair(P, Q, seg_off, out=None, workspace=None):
     if _is_torch(P):
         import torch
         n = P.numel() // G1_BYTES
-        if Q.numel() // G2_BYTES != n:
+        if not _is_torch(Q) or Q.numel() // G2_BYTES != n:
             raise ValueError("invalid inputs sizes")
         if not _is_torch(seg_off):
             # segment table on the host: the engine can cut segments into chunks that share their Miller squarings
@@ -140,8 +184,12 @@ def multi_pair(P, Q, seg_off, out=None, workspace=None):
             if k < 1 or int(seg[-1]) != n:
                 raise ValueError("invalid inputs sizes")
             out = _tnew(P, k, GT_BYTES) if out is None else out
+            _tchk(P, (P, n * G1_BYTES, "P"), (Q, n * G2_BYTES, "Q"), (out, k * GT_BYTES, "out"))
             _lib.check(lib.gpbc_multi_pair_hostseg_dev(_tptr(P), _tptr(Q), _ptr(seg), _sz(k), _tptr(out), _torch_stream()))
             return out
+        # segment table in device memory: it is read as k+1 uint64 by the kernel, so its dtype and size are checked here
+        if seg_off.dtype not in (torch.int64, torch.uint64) or not seg_off.is_cuda or not seg_off.is_contiguous() or seg_off.device != P.device:
+            raise ValueError("a device segment table must be a contiguous int64 / uint64 CUDA tensor on the points' device")
         k = seg_off.numel() - 1
         if k < 1 or int(seg_off[0].item()) != 0 or int(seg_off[-1].item()) != n:
             raise ValueError("invalid inputs sizes")          # the segment table must cover exactly the n pairs
@@ -149,6 +197,9 @@ def multi_pair(P, Q, seg_off, out=None, workspace=None):
         wsb = lib.gpbc_multi_pair_workspace_bytes(n, k)
         if workspace is None:
             workspace = torch.empty(max(wsb, 1), dtype=torch.uint8, device=P.device)
+        if workspace.numel() < wsb:
+            raise ValueError("workspace holds %d bytes, needs %d" % (workspace.numel(), wsb))
+        _tchk(P, (P, n * G1_BYTES, "P"), (Q, n * G2_BYTES, "Q"), (out, k * GT_BYTES, "out"), (workspace, workspace.numel(), "workspace"))
         _lib.check(lib.gpbc_multi_pair_dev(_tptr(P), _tptr(Q), ctypes.c_void_p(seg_off.data_ptr()), _sz(n), _sz(k),
                                            _tptr(out), _tptr(workspace), _sz(workspace.numel()), _torch_stream()))
         return out
@@ -168,11 +219,14 @@ def multi_pair_fixed_q(P, Q):
     _ensure_init()
     lib = _lib.load()
     if _is_torch(P):
+        if not _is_torch(Q):
+            raise ValueError("invalid inputs sizes")
         m = Q.numel() // G2_BYTES
         n = P.numel() // G1_BYTES
         if m < 1 or n < m or n % m:
             raise ValueError("invalid inputs sizes")
         out = _tnew(P, n // m, GT_BYTES)
+        _tchk(P, (P, n * G1_BYTES, "P"), (Q, m * G2_BYTES, "Q"))
         _lib.check(lib.gpbc_multi_pair_fixed_q_dev(_tptr(P), _tptr(Q), _sz(m), _sz(n // m), _tptr(out), _torch_stream()))
         return out
     P, Q = _np(P, G1_BYTES), _np(Q, G2_BYTES)
@@ -221,6 +275,7 @@ def miller_loop(P, Q):
     if _is_torch(P):
         n = P.numel() // G1_BYTES
         out = _tnew(P, n, GT_BYTES)
+        _tchk(P, (P, n * G1_BYTES, "P"), (Q, n * G2_BYTES, "Q"))
         _lib.check(lib.gpbc_miller_loop_dev(_tptr(P), _tptr(Q), _sz(n), _tptr(out), _torch_stream()))
         return out
     P, Q = _np(P, G1_BYTES), _np(Q, G2_BYTES)
@@ -236,6 +291,7 @@ def final_exp(F):
     if _is_torch(F):
         n = F.numel() // GT_BYTES
         out = _tnew(F, n, GT_BYTES)
+        _tchk(F, (F, n * GT_BYTES, "F"))
         _lib.check(lib.gpbc_final_exp_dev(_tptr(F), _sz(n), _tptr(out), _torch_stream()))
         return out
     F = _np(F, GT_BYTES)
@@ -250,11 +306,14 @@ def _scalar_mul(width, host_fn, dev_fn, bases, scalars, out):
     _ensure_init()
     scalars = scalars_to_bytes(scalars)
     if _is_torch(scalars):
+        if not _is_torch(bases):
+            raise ValueError("bases and scalars must both be CUDA tensors (or both host buffers)")
         n = scalars.numel() // SCALAR_BYTES
         nbase = bases.numel() // width
         if nbase not in (1, n):
             raise ValueError("need one base or one base per scalar")
         out = _tnew(scalars, n, width) if out is None else out
+        _tchk(scalars, (scalars, n * SCALAR_BYTES, "scalars"), (bases, nbase * width, "bases"), (out, n * width, "out"))
         _lib.check(dev_fn(_tptr(bases), _sz(nbase), _tptr(scalars), _sz(n), _tptr(out), _torch_stream()))
         return out
     bases, scalars = _np(bases, width), _np(scalars, SCALAR_BYTES)
@@ -295,6 +354,7 @@ def _sum(width, is_g2, host_fn, dev_fn, pts):
         out = _tnew(pts, 1, width)
         wsb = lib.gpbc_sum_workspace_bytes(n, is_g2)
         ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=pts.device)
+        _tchk(pts, (pts, n * width, "points"))
         _lib.check(dev_fn(_tptr(pts), _sz(n), _tptr(out), _tptr(ws), _sz(ws.numel()), _torch_stream()))
         return out[0]
     pts = _np(pts, width)
@@ -314,6 +374,89 @@ def g2_sum(pts):
     return _sum(G2_BYTES, 1, lib.gpbc_g2_sum, lib.gpbc_g2_sum_dev, pts)
 
 
+def _scalar_mul_sum(width, host_fn, dev_fn, bases, scalars):
+    _ensure_init()
+    scalars = scalars_to_bytes(scalars)
+    if _is_torch(scalars):
+        if not _is_torch(bases):
+            raise ValueError("bases and scalars must both be CUDA tensors (or both host buffers)")
+        n = scalars.numel() // SCALAR_BYTES
+        out = _tnew(scalars, 1, width)
+        _tchk(scalars, (scalars, n * SCALAR_BYTES, "scalars"), (bases, n * width, "bases"))
+        _lib.check(dev_fn(_tptr(bases), _tptr(scalars), _sz(n), _tptr(out), _torch_stream()))
+        return out[0]
+    bases, scalars = _np(bases, width), _np(scalars, SCALAR_BYTES)
+    n = scalars.size // SCALAR_BYTES
+    if bases.size // width != n:
+        raise ValueError("need one base per scalar")
+    out = np.empty(width, dtype=np.uint8)
+    _lib.check(host_fn(_ptr(bases), _ptr(scalars), _sz(n), _ptr(out)))
+    return out
+
+
+def g1_scalar_mul_sum(bases, scalars):
+    """sum_i [s_i] P_i (the verifier's sums of BLS aggregate verification, BASELINE config 3).  Host buffers: sharded over the
+    bound devices.  CUDA tensors: this rank's shard; with a communicator (comm_init_rank) the result is the sum over ALL
+    ranks — one RCCL all-gather of a point per rank inside the library."""
+    lib = _lib.load()
+    return _scalar_mul_sum(G1_BYTES, lib.gpbc_g1_scalar_mul_sum, lib.gpbc_g1_scalar_mul_sum_dev, bases, scalars)
+
+
+def g2_scalar_mul_sum(bases, scalars):
+    lib = _lib.load()
+    return _scalar_mul_sum(G2_BYTES, lib.gpbc_g2_scalar_mul_sum, lib.gpbc_g2_scalar_mul_sum_dev, bases, scalars)
+
+
+# --------------------------------------------------------------------------------------- collectives (RCCL inside the library)
+COMM_ID_BYTES = 128
+
+
+def comm_init_all():
+    """One RCCL communicator over all bound devices of this process (rank = device slot)."""
+    _ensure_init()
+    _lib.check(_lib.load().gpbc_comm_init_all())
+
+
+def comm_unique_id():
+    """128 opaque bytes from rank 0, to be handed to every rank's comm_init_rank (any transport: torch.distributed
+    broadcast, a file, the launcher's environment)."""
+    buf = (ctypes.c_uint8 * COMM_ID_BYTES)()
+    _lib.check(_lib.load().gpbc_comm_get_unique_id(buf))
+    return bytes(buf)
+
+
+def comm_init_rank(unique_id, n_ranks, rank):
+    """Join the multi-process communicator as `rank` with this process's current device (one process per GPU)."""
+    _ensure_init()
+    if len(unique_id) != COMM_ID_BYTES:
+        raise ValueError("the communicator id is %d bytes" % COMM_ID_BYTES)
+    buf = (ctypes.c_uint8 * COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
+    _lib.check(_lib.load().gpbc_comm_init_rank(buf, ctypes.c_int(n_ranks), ctypes.c_int(rank)))
+
+
+def comm_ranks():
+    return int(_lib.load().gpbc_comm_ranks())
+
+
+def comm_destroy():
+    _lib.check(_lib.load().gpbc_comm_destroy())
+
+
+def allgather(send, out=None):
+    """All-gather equal-sized uint8 CUDA blocks over the library's communicator: returns [n_ranks, send.numel()].
+    Enqueued on the current torch stream, not synchronised."""
+    _ensure_init()
+    import torch
+    ranks = comm_ranks()
+    if ranks < 1:
+        raise EngineError("no communicator: call comm_init_rank() / comm_init_all() first")
+    nb = send.numel()
+    out = torch.empty((ranks, nb), dtype=torch.uint8, device=send.device) if out is None else out
+    _tchk(send, (send, nb, "send"), (out, ranks * nb, "out"))
+    _lib.check(_lib.load().gpbc_allgather_dev(_tptr(send), _sz(nb), _tptr(out), _torch_stream()))
+    return out
+
+
 # --------------------------------------------------------------------------------------- GT
 def gt_exp(x, k, out=None):
     """out[i] = new(GT).Exp(x[i], k[i]); Python ints may be negative (inverse, as gnark)."""
@@ -331,7 +474,11 @@ def gt_exp(x, k, out=None):
         k = np.frombuffer(b"".join(int(s).to_bytes(32, "little") for s in k), dtype=np.uint8)
     if _is_torch(x):
         n = x.numel() // GT_BYTES
+        if not _is_torch(k):
+            import torch
+            k = torch.from_numpy(np.ascontiguousarray(_np(k, SCALAR_BYTES)).copy()).to(x.device)
         out = _tnew(x, n, GT_BYTES) if out is None else out
+        _tchk(x, (x, n * GT_BYTES, "x"), (k, n * SCALAR_BYTES, "k"), (out, n * GT_BYTES, "out"))
         _lib.check(lib.gpbc_gt_exp_batch_dev(_tptr(x), _tptr(k), _sz(n), _tptr(out), _torch_stream()))
         return out
     x, k = _np(x, GT_BYTES), _np(k, SCALAR_BYTES)
@@ -348,6 +495,7 @@ def _gt_binary(host_fn, dev_fn, a, b):
     if _is_torch(a):
         n = a.numel() // GT_BYTES
         out = _tnew(a, n, GT_BYTES)
+        _tchk(a, (a, n * GT_BYTES, "a"), (b, n * GT_BYTES, "b"))
         _lib.check(dev_fn(_tptr(a), _tptr(b), _sz(n), _tptr(out), _torch_stream()))
         return out
     a, b = _np(a, GT_BYTES), _np(b, GT_BYTES)
@@ -375,6 +523,7 @@ def gt_inverse(a):
     if _is_torch(a):
         n = a.numel() // GT_BYTES
         out = _tnew(a, n, GT_BYTES)
+        _tchk(a, (a, n * GT_BYTES, "a"))
         _lib.check(lib.gpbc_gt_inverse_batch_dev(_tptr(a), _sz(n), _tptr(out), _torch_stream()))
         return out
     a = _np(a, GT_BYTES)
@@ -413,6 +562,7 @@ def _marshal(kind, x, compressed):
     if _is_torch(x):
         n = x.numel() // mem
         out = _tnew(x, n, width)
+        _tchk(x, (x, n * mem, kind + " elements"))
         _lib.check(dev(_tptr(x), _sz(n), *cflag, _tptr(out), _torch_stream()))
         return out
     x = _np(x, mem)
@@ -440,6 +590,7 @@ def _unmarshal(kind, buf, elem_bytes):
         n = buf.numel() // elem_bytes
         out = _tnew(buf, n, mem)
         ok = torch.empty((n,), dtype=torch.uint8, device=buf.device)
+        _tchk(buf, (buf, n * elem_bytes, kind + " encodings"))
         _lib.check(dev(_tptr(buf), *eb, _sz(n), _tptr(out), _tptr(ok), _torch_stream()))
         return out, ok
     buf = _np(buf, elem_bytes)
@@ -488,6 +639,7 @@ def _map_fields(width, host_fn, dev_fn, u):
     if _is_torch(u):
         n = u.numel() // width
         out = _tnew(u, n, width)
+        _tchk(u, (u, n * width, "field elements"))
         _lib.check(dev_fn(_tptr(u), _sz(n), _tptr(out), _torch_stream()))
         return out
     u = _np(u, width)
@@ -528,6 +680,7 @@ class FixedBase:
         self._h = ctypes.c_void_p()
         if _is_torch(bases):
             self.nbase = bases.numel() // self.width
+            _tchk(bases, (bases, self.nbase * self.width, "bases"))
             _lib.check(self._lib.gpbc_fixed_base_create_dev(ctypes.c_int(1 if g2 else 0), _tptr(bases), _sz(self.nbase),
                                                             _torch_stream(), ctypes.byref(self._h)))
             import torch
@@ -546,8 +699,11 @@ class FixedBase:
             else scalars_to_bytes([s for row in scalars for s in row])
         if _is_torch(k):
             import torch
+            if k.numel() % (SCALAR_BYTES * self.nbase):
+                raise ValueError("need nbase = %d scalars per sum" % self.nbase)
             n = k.numel() // (SCALAR_BYTES * self.nbase)
             out = _tnew(k, n, self.width)
+            _tchk(k, (k, n * self.nbase * SCALAR_BYTES, "scalars"))
             wsb = int(self._lib.gpbc_fixed_base_msm_workspace_bytes(self._h, _sz(n)))
             ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=k.device)
             _lib.check(self._lib.gpbc_fixed_base_msm_dev(self._h, _tptr(k), _sz(n), _tptr(out), _tptr(ws), _sz(wsb), _torch_stream()))

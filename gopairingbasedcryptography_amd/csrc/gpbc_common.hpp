@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <vector>
 #include "../../include/gpbc_bn254.h"
@@ -46,11 +47,25 @@ __device__ __forceinline__ void g2_store_aff(uint8_t *p, const AffP<F2> &r) { f2
 
 // ---- host side
 extern thread_local char g_err[512];
-extern std::atomic<int> g_device;
 int fail(int code, const char *fmt, ...);
 #define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(GPBC_ERR_HIP, "%s failed: %s", #x, hipGetErrorString(e_)); } while (0)
 #define TRY(x) do { int rc_ = (x); if (rc_ != GPBC_OK) return rc_; } while (0)
+// Devices: gpbc_init_devices() binds the process to a LIST of HIP devices.  Every host thread has a current device
+// (gpbc_set_device, thread-local, default = the first of the list): *_dev entries and the un-sharded host entries run
+// there.  bind_device() makes it the calling thread's HIP device; current_device() is its HIP ordinal (-1 before init).
 int bind_device();
+int current_device();
+int device_count_initialised();
+// Host-pointer batch entries over n independent units: with more than one device initialised the range [0, n) is cut by
+// shard_range (contiguous, sizes differ by at most one) and each part runs on its own device from its own host thread
+// (body(lo, hi) is called with that thread's current device set); one device, a batch below 2 * min_units or a call made
+// from inside a shard run body(0, n) on the calling thread.  Returns the first failing status (its message becomes the
+// caller's gpbc_last_error()).
+int run_sharded(size_t n, size_t min_units, const std::function<int(size_t, size_t)> &body);
+// RCCL communicator of the current device (gpbc_core.hip): number of ranks (0 = none), this device's rank, all-gather
+int comm_ranks();
+int comm_rank();
+int comm_allgather(const void *d_send, size_t bytes, void *d_recv, hipStream_t st);
 static inline unsigned grid_for(size_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
 int check_launch(const char *what);
 int sync_default();
@@ -86,7 +101,8 @@ constexpr size_t LINE_BYTES_PER_PAIR = (size_t)88 * 54 * sizeof(int32_t);
 // Held while a call enqueues the kernels that share the stream's workspace (lines then accumulate; table build and loop
 // in one kernel): two host threads launching on the same stream must not interleave such sequences.  Enqueueing is
 // asynchronous, so the lock is held for microseconds.
-extern std::mutex g_ws_seq_mu;
+std::mutex &ws_seq_mutex();                                             // of the calling thread's current device
+#define g_ws_seq_mu (ws_seq_mutex())
 int stream_workspace(hipStream_t stream, size_t bytes, int32_t **out);
 static inline int lines_workspace(hipStream_t stream, size_t pairs, int32_t **out) { return stream_workspace(stream, pairs * LINE_BYTES_PER_PAIR, out); }
 void free_workspaces();

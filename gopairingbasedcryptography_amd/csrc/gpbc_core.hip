@@ -1,10 +1,14 @@
-// libgpbc_bn254.so, unit 1 of 4: process-wide state and lifetime entries of the C ABI (include/gpbc_bn254.h), the per-stream
-// internal workspace, and the field-level test entry.  gfx950 only.
+// libgpbc_bn254.so, unit 1 of 4: process-wide state and lifetime entries of the C ABI (include/gpbc_bn254.h): the list of
+// bound devices with a thread-local current device, host-side sharding of batch entries over the devices, the RCCL
+// communicator(s) and the all-gather entries, the per-(device, stream) internal workspace, and the field-level test
+// entry.  gfx950 only.
 #include "gpbc_common.hpp"
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types and enums only: the library is opened with dlopen when a communicator is first asked for
+#include <string>
+#include <thread>
 
 thread_local char g_err[512] = "";
-std::atomic<int> g_device{-1};
-std::mutex g_ws_seq_mu;
 
 int fail(int code, const char *fmt, ...) {
     va_list ap;
@@ -13,11 +17,39 @@ int fail(int code, const char *fmt, ...) {
     va_end(ap);
     return code;
 }
+
+// ---- devices.  Slots are written under g_dev_mu by init / shutdown and read lock-free afterwards (g_ndev is published
+// last); a slot's mutex and communicator live as long as the process.
+constexpr int MAX_DEVICES = 64;
+struct DeviceCtx {
+    int hip = -1;                 // HIP ordinal
+    std::mutex ws_seq;            // held while a call enqueues kernels that share this device's stream workspace
+    ncclComm_t comm = nullptr;    // RCCL communicator of this device (rank = comm_rank of comm_ranks), or null
+};
+static DeviceCtx g_ctx[MAX_DEVICES];
+static std::atomic<int> g_ndev{0};
+static std::mutex g_dev_mu;
+static std::atomic<int> g_host_sharding{1};
+static thread_local int tl_index = -1;        // current device of this thread (index into g_ctx); -1 = the first
+static thread_local bool tl_in_shard = false;
+
+static inline int cur_index() { return tl_index < 0 ? 0 : tl_index; }
+int device_count_initialised() { return g_ndev.load(); }
+int current_device() {
+    int n = g_ndev.load();
+    if (n <= 0) return -1;
+    int i = cur_index();
+    return g_ctx[i < n ? i : 0].hip;
+}
 int bind_device() {
-    int d = g_device.load();
+    int d = current_device();
     if (d < 0) return fail(GPBC_ERR_NO_DEVICE, "gpbc_init() has not bound a HIP device (no CPU fallback exists)");
     HIP_TRY(hipSetDevice(d));
     return GPBC_OK;
+}
+std::mutex &ws_seq_mutex() {
+    int n = g_ndev.load(), i = cur_index();
+    return g_ctx[(n > 0 && i < n) ? i : 0].ws_seq;
 }
 int check_launch(const char *what) {
     hipError_t e = hipGetLastError();
@@ -26,11 +58,42 @@ int check_launch(const char *what) {
 }
 int sync_default() { HIP_TRY(hipStreamSynchronize(nullptr)); return GPBC_OK; }
 
-struct StreamWs { int device; hipStream_t stream; void *ptr; size_t bytes; };
+static inline void shard_range(size_t n, size_t part, size_t parts, size_t *lo, size_t *hi) {
+    size_t base = n / parts, extra = n % parts;
+    *lo = part * base + (part < extra ? part : extra);
+    *hi = *lo + base + (part < extra ? 1 : 0);
+}
+int run_sharded(size_t n, size_t min_units, const std::function<int(size_t, size_t)> &body) {
+    const int nd = g_ndev.load();
+    if (min_units < 1) min_units = 1;
+    if (nd <= 1 || tl_in_shard || !g_host_sharding.load() || n < 2 * min_units) return body(0, n);
+    size_t parts = n / min_units;
+    if (parts > (size_t)nd) parts = (size_t)nd;
+    std::vector<int> rc(parts, GPBC_OK);
+    std::vector<std::string> msg(parts);
+    std::vector<std::thread> th;
+    th.reserve(parts);
+    for (size_t d = 0; d < parts; d++)
+        th.emplace_back([&, d]() {
+            tl_index = (int)d;
+            tl_in_shard = true;
+            size_t lo, hi;
+            shard_range(n, d, parts, &lo, &hi);
+            rc[d] = body(lo, hi);
+            if (rc[d] != GPBC_OK) msg[d] = g_err;
+        });
+    for (auto &t : th) t.join();
+    for (size_t d = 0; d < parts; d++)
+        if (rc[d] != GPBC_OK) return fail(rc[d], "device %d (shard %zu of %zu): %s", g_ctx[d].hip, d, parts, msg[d].c_str());
+    return GPBC_OK;
+}
+
+// ---- internal workspace, one grow-only buffer per (bound device slot, stream)
+struct StreamWs { int device; hipStream_t stream; void *ptr; size_t bytes; };      // device = index into g_ctx
 static std::mutex g_ws_mu;
 static std::vector<StreamWs> g_ws;
 int stream_workspace(hipStream_t stream, size_t bytes, int32_t **out) {
-    int dev = g_device.load();
+    int dev = cur_index();
     std::lock_guard<std::mutex> lk(g_ws_mu);
     for (auto &w : g_ws)
         if (w.device == dev && w.stream == stream) {
@@ -52,8 +115,70 @@ int stream_workspace(hipStream_t stream, size_t bytes, int32_t **out) {
 }
 void free_workspaces() {
     std::lock_guard<std::mutex> lk(g_ws_mu);
-    for (auto &w : g_ws) if (w.ptr) { (void)hipSetDevice(w.device); (void)hipFree(w.ptr); }
+    for (auto &w : g_ws) if (w.ptr) { if (g_ctx[w.device].hip >= 0) (void)hipSetDevice(g_ctx[w.device].hip); (void)hipFree(w.ptr); }
     g_ws.clear();
+}
+
+// ---- RCCL, opened on demand.  A process that already carries an RCCL (PyTorch-ROCm ships one and torch.distributed uses
+// it) must not get a second copy, so an already loaded library is taken first.
+struct Rccl {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+static Rccl g_rccl;
+static std::mutex g_rccl_mu;
+static int g_comm_ranks = 0;          // 0: no communicator
+static int g_comm_mode = 0;           // 1: one communicator per bound device in this process, 2: one rank of a multi-process job
+static int g_comm_rank0 = 0;          // mode 2: this process's rank
+static int rccl_load() {
+    if (g_rccl.handle) return GPBC_OK;
+    void *h = nullptr;
+    for (const char *name : {"librccl.so", "librccl.so.1"}) if ((h = dlopen(name, RTLD_NOW | RTLD_NOLOAD))) break;
+    if (!h) for (const char *name : {"librccl.so.1", "librccl.so"}) if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!h) return fail(GPBC_ERR_COMM, "RCCL not found (dlopen librccl.so.1): %s", dlerror());
+    Rccl r;
+    r.handle = h;
+#define GPBC_SYM(field, sym) *(void **)(&r.field) = dlsym(h, sym); if (!r.field) return fail(GPBC_ERR_COMM, "RCCL symbol %s missing", sym)
+    GPBC_SYM(GetUniqueId, "ncclGetUniqueId");
+    GPBC_SYM(CommInitRank, "ncclCommInitRank");
+    GPBC_SYM(CommInitAll, "ncclCommInitAll");
+    GPBC_SYM(CommDestroy, "ncclCommDestroy");
+    GPBC_SYM(AllGather, "ncclAllGather");
+    GPBC_SYM(GroupStart, "ncclGroupStart");
+    GPBC_SYM(GroupEnd, "ncclGroupEnd");
+    GPBC_SYM(GetErrorString, "ncclGetErrorString");
+#undef GPBC_SYM
+    g_rccl = r;
+    return GPBC_OK;
+}
+#define NCCL_TRY(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) return fail(GPBC_ERR_COMM, "%s failed: %s", #x, g_rccl.GetErrorString(r_)); } while (0)
+static void comm_destroy_locked() {
+    const int n = g_ndev.load();
+    for (int i = 0; i < MAX_DEVICES; i++)
+        if (g_ctx[i].comm) {
+            if (i < n) (void)hipSetDevice(g_ctx[i].hip);
+            if (g_rccl.CommDestroy) (void)g_rccl.CommDestroy(g_ctx[i].comm);
+            g_ctx[i].comm = nullptr;
+        }
+    g_comm_ranks = 0; g_comm_mode = 0; g_comm_rank0 = 0;
+}
+int comm_ranks() { return g_comm_ranks; }
+int comm_rank() { return g_comm_mode == 2 ? g_comm_rank0 : cur_index(); }
+// all-gather on the communicator of the calling thread's current device
+int comm_allgather(const void *d_send, size_t bytes, void *d_recv, hipStream_t st) {
+    if (!g_comm_ranks) return fail(GPBC_ERR_COMM, "no communicator: call gpbc_comm_init_all() or gpbc_comm_init_rank() first");
+    const int n = g_ndev.load(), i = cur_index();
+    ncclComm_t c = (i < n) ? g_ctx[i].comm : nullptr;
+    if (!c) return fail(GPBC_ERR_COMM, "the current device (index %d) has no communicator", i);
+    NCCL_TRY(g_rccl.AllGather(d_send, d_recv, bytes, ncclUint8, c, st));
+    return GPBC_OK;
 }
 
 __global__ void __launch_bounds__(BLOCK) k_fp_mul(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, uint8_t *__restrict__ out, size_t n) {
@@ -64,7 +189,7 @@ __global__ void __launch_bounds__(BLOCK) k_fp_mul(const uint8_t *__restrict__ a,
 
 extern "C" {
 
-int gpbc_abi_version(void) { return 4; }
+int gpbc_abi_version(void) { return 5; }
 const char *gpbc_last_error(void) { return g_err; }
 
 int gpbc_device_count(void) {
@@ -74,22 +199,124 @@ int gpbc_device_count(void) {
     return n;
 }
 
-int gpbc_init(int device) {
+int gpbc_init_devices(const int *devices, int n_devices) {
+    if (!devices || n_devices < 1) return fail(GPBC_ERR_INVALID_ARG, "gpbc_init_devices needs at least one device");
+    if (n_devices > MAX_DEVICES) return fail(GPBC_ERR_INVALID_ARG, "at most %d devices", MAX_DEVICES);
     int n = gpbc_device_count();
     if (n <= 0) return fail(GPBC_ERR_NO_DEVICE, "no HIP device visible (this engine has no CPU fallback)");
-    if (device < 0 || device >= n) return fail(GPBC_ERR_INVALID_ARG, "device %d out of range [0,%d)", device, n);
-    HIP_TRY(hipSetDevice(device));
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device));
-    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-        return fail(GPBC_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
-    g_device.store(device);
+    for (int i = 0; i < n_devices; i++) {
+        if (devices[i] < 0 || devices[i] >= n) return fail(GPBC_ERR_INVALID_ARG, "device %d out of range [0,%d)", devices[i], n);
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, devices[i]));
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return fail(GPBC_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 code only", devices[i], prop.gcnArchName);
+    }
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    bool same = g_ndev.load() == n_devices;
+    for (int i = 0; same && i < n_devices; i++) same = g_ctx[i].hip == devices[i];
+    if (same) return GPBC_OK;                                   // idempotent
+    if (g_ndev.load() > 0) {                                    // a different list: drop what belongs to the old one
+        std::lock_guard<std::mutex> ck(g_rccl_mu);
+        comm_destroy_locked();
+        free_workspaces();
+        g_ndev.store(0);
+    }
+    for (int i = 0; i < n_devices; i++) g_ctx[i].hip = devices[i];
+    g_ndev.store(n_devices);
+    HIP_TRY(hipSetDevice(devices[0]));
+    return GPBC_OK;
+}
+int gpbc_init(int device) { return gpbc_init_devices(&device, 1); }
+int gpbc_num_devices(void) { return g_ndev.load(); }
+int gpbc_device_at(int index) {
+    if (index < 0 || index >= g_ndev.load()) return fail(GPBC_ERR_INVALID_ARG, "device index %d out of range [0,%d)", index, g_ndev.load());
+    return g_ctx[index].hip;
+}
+int gpbc_set_device(int index) {
+    if (index < 0 || index >= g_ndev.load()) return fail(GPBC_ERR_INVALID_ARG, "device index %d out of range [0,%d)", index, g_ndev.load());
+    tl_index = index;
+    return GPBC_OK;
+}
+int gpbc_get_device(void) { return g_ndev.load() > 0 ? cur_index() : fail(GPBC_ERR_NO_DEVICE, "gpbc_init() has not bound a HIP device"); }
+int gpbc_set_host_sharding(int on) { g_host_sharding.store(on ? 1 : 0); return GPBC_OK; }
+
+int gpbc_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    {
+        std::lock_guard<std::mutex> ck(g_rccl_mu);
+        comm_destroy_locked();
+    }
+    free_workspaces();
+    g_ndev.store(0);
+    for (int i = 0; i < MAX_DEVICES; i++) g_ctx[i].hip = -1;
     return GPBC_OK;
 }
 
-int gpbc_shutdown(void) {
-    free_workspaces();
-    g_device.store(-1);
+// ---- RCCL communicators and the all-gather (the only collective of this path)
+int gpbc_comm_init_all(void) {
+    const int n = g_ndev.load();
+    if (n <= 0) return fail(GPBC_ERR_NO_DEVICE, "gpbc_init_devices() first");
+    std::lock_guard<std::mutex> ck(g_rccl_mu);
+    if (g_comm_mode == 1 && g_comm_ranks == n) return GPBC_OK;
+    TRY(rccl_load());
+    comm_destroy_locked();
+    ncclComm_t comms[MAX_DEVICES];
+    int devs[MAX_DEVICES];
+    for (int i = 0; i < n; i++) devs[i] = g_ctx[i].hip;
+    NCCL_TRY(g_rccl.CommInitAll(comms, n, devs));
+    for (int i = 0; i < n; i++) g_ctx[i].comm = comms[i];
+    g_comm_ranks = n; g_comm_mode = 1;
+    return GPBC_OK;
+}
+int gpbc_comm_get_unique_id(void *id_out) {
+    if (!id_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    std::lock_guard<std::mutex> ck(g_rccl_mu);
+    TRY(rccl_load());
+    ncclUniqueId id;
+    NCCL_TRY(g_rccl.GetUniqueId(&id));
+    memcpy(id_out, &id, GPBC_COMM_ID_BYTES);
+    return GPBC_OK;
+}
+int gpbc_comm_init_rank(const void *id_in, int n_ranks, int rank) {
+    if (!id_in) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(GPBC_ERR_INVALID_ARG, "rank %d of %d", rank, n_ranks);
+    TRY(bind_device());
+    std::lock_guard<std::mutex> ck(g_rccl_mu);
+    TRY(rccl_load());
+    comm_destroy_locked();
+    ncclUniqueId id;
+    memcpy(&id, id_in, GPBC_COMM_ID_BYTES);
+    ncclComm_t c = nullptr;
+    NCCL_TRY(g_rccl.CommInitRank(&c, n_ranks, id, rank));
+    g_ctx[cur_index()].comm = c;
+    g_comm_ranks = n_ranks; g_comm_mode = 2; g_comm_rank0 = rank;
+    return GPBC_OK;
+}
+int gpbc_comm_ranks(void) { return g_comm_ranks; }
+int gpbc_comm_rank(void) { return g_comm_ranks ? comm_rank() : fail(GPBC_ERR_COMM, "no communicator"); }
+int gpbc_comm_destroy(void) {
+    std::lock_guard<std::mutex> ck(g_rccl_mu);
+    comm_destroy_locked();
+    return GPBC_OK;
+}
+int gpbc_allgather_dev(const void *d_send, size_t bytes_per_rank, void *d_recv, void *stream) {
+    if (!bytes_per_rank) return GPBC_OK;
+    if (!d_send || !d_recv) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    TRY(bind_device());
+    return comm_allgather(d_send, bytes_per_rank, d_recv, (hipStream_t)stream);
+}
+int gpbc_allgather_all_dev(const void *const *d_send, size_t bytes_per_rank, void *const *d_recv, void *const *streams) {
+    if (!bytes_per_rank) return GPBC_OK;
+    if (!d_send || !d_recv) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    if (g_comm_mode != 1) return fail(GPBC_ERR_COMM, "gpbc_allgather_all_dev needs gpbc_comm_init_all()");
+    const int n = g_comm_ranks;
+    for (int i = 0; i < n; i++) if (!d_send[i] || !d_recv[i]) return fail(GPBC_ERR_INVALID_ARG, "null pointer for device index %d", i);
+    NCCL_TRY(g_rccl.GroupStart());
+    for (int i = 0; i < n; i++) {
+        ncclResult_t r = g_rccl.AllGather(d_send[i], d_recv[i], bytes_per_rank, ncclUint8, g_ctx[i].comm, streams ? (hipStream_t)streams[i] : nullptr);
+        if (r != ncclSuccess) { (void)g_rccl.GroupEnd(); return fail(GPBC_ERR_COMM, "ncclAllGather (device index %d) failed: %s", i, g_rccl.GetErrorString(r)); }
+    }
+    NCCL_TRY(g_rccl.GroupEnd());
     return GPBC_OK;
 }
 

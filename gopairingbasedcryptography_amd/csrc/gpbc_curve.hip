@@ -230,10 +230,7 @@ static int sum_dev(bool g2, const void *d_pts, size_t n, void *d_out, void *d_ws
 int gpbc_g1_sum_dev(const void *p, size_t n, void *o, void *w, size_t wb, void *s) { return sum_dev(false, p, n, o, w, wb, s); }
 int gpbc_g2_sum_dev(const void *p, size_t n, void *o, void *w, size_t wb, void *s) { return sum_dev(true, p, n, o, w, wb, s); }
 
-static int scalar_mul_host(bool g2, const void *bases, size_t nbase, const void *scalars, size_t n, void *out) {
-    if (!n) return GPBC_OK;
-    if (!bases || !scalars || !out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
-    if (nbase != 1 && nbase != n) return fail(GPBC_ERR_INVALID_ARG, "nbase must be 1 or n");
+static int scalar_mul_one(bool g2, const void *bases, size_t nbase, const void *scalars, size_t n, void *out) {
     TRY(bind_device());
     size_t pt = g2 ? GPBC_G2_BYTES : GPBC_G1_BYTES;
     DevBuf dB, dS, dO;
@@ -242,11 +239,23 @@ static int scalar_mul_host(bool g2, const void *bases, size_t nbase, const void 
     TRY(sync_default());
     return dO.download(out, n * pt);
 }
+// host-pointer entries shard [0, n) over the bound devices (run_sharded, gpbc_core.hip)
+constexpr size_t SMUL_SHARD_MIN = 4096;
+static int scalar_mul_host(bool g2, const void *bases, size_t nbase, const void *scalars, size_t n, void *out) {
+    if (!n) return GPBC_OK;
+    if (!bases || !scalars || !out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    if (nbase != 1 && nbase != n) return fail(GPBC_ERR_INVALID_ARG, "nbase must be 1 or n");
+    const size_t pt = g2 ? GPBC_G2_BYTES : GPBC_G1_BYTES;
+    return run_sharded(n, SMUL_SHARD_MIN, [=](size_t lo, size_t hi) {
+        const bool shared = nbase == 1 && n != 1;
+        return scalar_mul_one(g2, (const uint8_t *)bases + (shared ? 0 : lo * pt), shared ? 1 : hi - lo, (const uint8_t *)scalars + lo * GPBC_SCALAR_BYTES,
+                              hi - lo, (uint8_t *)out + lo * pt);
+    });
+}
 int gpbc_g1_scalar_mul_batch(const void *b, size_t nb, const void *s, size_t n, void *o) { return scalar_mul_host(false, b, nb, s, n, o); }
 int gpbc_g2_scalar_mul_batch(const void *b, size_t nb, const void *s, size_t n, void *o) { return scalar_mul_host(true, b, nb, s, n, o); }
 
-static int sum_host(bool g2, const void *pts, size_t n, void *out) {
-    if (!out || (n && !pts)) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+static int sum_one(bool g2, const void *pts, size_t n, void *out) {
     TRY(bind_device());
     size_t pt = g2 ? GPBC_G2_BYTES : GPBC_G1_BYTES;
     DevBuf dP, dO, dW;
@@ -257,6 +266,117 @@ static int sum_host(bool g2, const void *pts, size_t n, void *out) {
     TRY(sync_default());
     return dO.download(out, pt);
 }
+// Partial sums of the shards of a host-pointer call, combined on the first device: one point per shard, exchanged by RCCL
+// (ONE all-gather of a point per rank, in-process group call) when gpbc_comm_init_all() made a communicator for every bound
+// device, through the host otherwise.  `partial(lo, hi, d_out)` leaves the shard's sum in device memory at d_out (stream 0).
+static int sharded_point_sum(bool g2, size_t n, size_t min_units, const std::function<int(size_t, size_t, uint8_t *)> &partial, void *out) {
+    const size_t pt = g2 ? GPBC_G2_BYTES : GPBC_G1_BYTES;
+    const int nd = device_count_initialised();
+    std::vector<uint8_t> parts((size_t)(nd > 0 ? nd : 1) * pt, 0);
+    std::vector<uint8_t *> d_part((size_t)(nd > 0 ? nd : 1), nullptr), d_all((size_t)(nd > 0 ? nd : 1), nullptr);
+    std::atomic<int> used{0};
+    const bool rccl = comm_ranks() == nd && nd > 1;
+    int rc = run_sharded(n, min_units, [&](size_t lo, size_t hi) {
+        TRY(bind_device());
+        const int idx = gpbc_get_device();
+        used.fetch_add(1);
+        uint8_t *dp = nullptr;
+        HIP_TRY(hipMalloc((void **)&dp, pt));
+        d_part[idx] = dp;
+        TRY(partial(lo, hi, dp));
+        TRY(sync_default());
+        HIP_TRY(hipMemcpy(parts.data() + (size_t)idx * pt, dp, pt, hipMemcpyDeviceToHost));   // used when no communicator spans the shards
+        return (int)GPBC_OK;
+    });
+    auto release = [&]() {
+        for (int i = 0; i < nd; i++) {
+            if (d_part[i] || d_all[i]) { (void)gpbc_set_device(i); (void)bind_device(); }
+            if (d_part[i]) (void)hipFree(d_part[i]);
+            if (d_all[i]) (void)hipFree(d_all[i]);
+        }
+        (void)gpbc_set_device(0);
+    };
+    const int before = gpbc_get_device();
+    if (rc == GPBC_OK && used.load() > 1 && rccl) {
+        // every rank contributes its point (ranks whose shard was empty contribute the point at infinity = zeros)
+        for (int i = 0; i < nd && rc == GPBC_OK; i++) {
+            (void)gpbc_set_device(i);
+            rc = bind_device();
+            if (rc == GPBC_OK && !d_part[i]) {
+                if (hipMalloc((void **)&d_part[i], pt) != hipSuccess || hipMemset(d_part[i], 0, pt) != hipSuccess) rc = fail(GPBC_ERR_HIP, "hipMalloc of a partial sum failed");
+            }
+            if (rc == GPBC_OK && hipMalloc((void **)&d_all[i], (size_t)nd * pt) != hipSuccess) rc = fail(GPBC_ERR_HIP, "hipMalloc of the gathered partial sums failed");
+        }
+        if (rc == GPBC_OK) rc = gpbc_allgather_all_dev((const void *const *)d_part.data(), pt, (void *const *)d_all.data(), nullptr);
+        (void)gpbc_set_device(0);
+        if (rc == GPBC_OK) rc = bind_device();
+        if (rc == GPBC_OK && hipStreamSynchronize(nullptr) != hipSuccess) rc = fail(GPBC_ERR_HIP, "hipStreamSynchronize failed after the all-gather");
+        if (rc == GPBC_OK && hipMemcpy(parts.data(), d_all[0], (size_t)nd * pt, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(GPBC_ERR_HIP, "download of the gathered partial sums failed");
+    }
+    release();
+    if (before >= 0) (void)gpbc_set_device(before);
+    if (rc != GPBC_OK) return rc;
+    if (used.load() == 1) { memcpy(out, parts.data() + (size_t)(before > 0 && before < nd ? before : 0) * pt, pt); return GPBC_OK; }
+    return sum_one(g2, parts.data(), (size_t)nd, out);               // rows of devices without a shard are the point at infinity
+}
+static int sum_host(bool g2, const void *pts, size_t n, void *out) {
+    if (!out || (n && !pts)) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    const size_t pt = g2 ? GPBC_G2_BYTES : GPBC_G1_BYTES;
+    if (device_count_initialised() <= 1 || n < 2 * 65536) return sum_one(g2, pts, n, out);
+    return sharded_point_sum(g2, n, 65536, [=](size_t lo, size_t hi, uint8_t *d_out) {
+        DevBuf dP, dW;
+        TRY(dP.upload((const uint8_t *)pts + lo * pt, (hi - lo) * pt));
+        const size_t wsb = gpbc_sum_workspace_bytes(hi - lo, g2);
+        TRY(dW.alloc(wsb));
+        TRY(sum_dev(g2, dP.p, hi - lo, d_out, dW.p, wsb, nullptr));
+        return sync_default();
+    }, out);
+}
+// sum_i [s_i] P_i, host pointers: scalar multiplications and the point-sum tree per shard, partial sums combined as above
+static int scalar_mul_sum_host(bool g2, const void *bases, const void *scalars, size_t n, void *out) {
+    if (!out || (n && (!bases || !scalars))) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    const size_t pt = g2 ? GPBC_G2_BYTES : GPBC_G1_BYTES;
+    if (!n) { memset(out, 0, pt); return GPBC_OK; }
+    return sharded_point_sum(g2, n, SMUL_SHARD_MIN, [=](size_t lo, size_t hi, uint8_t *d_out) {
+        const size_t m = hi - lo;
+        DevBuf dB, dS, dM, dW;
+        TRY(dB.upload((const uint8_t *)bases + lo * pt, m * pt)); TRY(dS.upload((const uint8_t *)scalars + lo * GPBC_SCALAR_BYTES, m * GPBC_SCALAR_BYTES));
+        TRY(dM.alloc(m * pt));
+        TRY(scalar_mul_dev(g2, dB.p, m, dS.p, m, dM.p, nullptr));
+        const size_t wsb = gpbc_sum_workspace_bytes(m, g2);
+        TRY(dW.alloc(wsb));
+        TRY(sum_dev(g2, dM.p, m, d_out, dW.p, wsb, nullptr));
+        return sync_default();
+    }, out);
+}
+int gpbc_g1_scalar_mul_sum(const void *b, const void *s, size_t n, void *o) { return scalar_mul_sum_host(false, b, s, n, o); }
+int gpbc_g2_scalar_mul_sum(const void *b, const void *s, size_t n, void *o) { return scalar_mul_sum_host(true, b, s, n, o); }
+// Device-resident form, one rank of a multi-process job: local sum, all-gather of one point per rank, sum of the partials.
+static int scalar_mul_sum_dev(bool g2, const void *d_bases, const void *d_scalars, size_t n, void *d_out, void *stream) {
+    if (!d_out || (n && (!d_bases || !d_scalars))) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    TRY(bind_device());
+    hipStream_t st = (hipStream_t)stream;
+    const size_t pt = g2 ? GPBC_G2_BYTES : GPBC_G1_BYTES;
+    const int ranks = comm_ranks();
+    const size_t wsb_local = gpbc_sum_workspace_bytes(n, g2), wsb_all = gpbc_sum_workspace_bytes((size_t)(ranks > 1 ? ranks : 1), g2);
+    // one stream-ordered scratch block: products | local tree workspace | local sum | gathered sums | final tree workspace
+    const size_t total = n * pt + wsb_local + pt + (size_t)(ranks > 1 ? ranks : 1) * pt + wsb_all;
+    uint8_t *mem = nullptr;
+    HIP_TRY(hipMallocAsync((void **)&mem, total, st));
+    uint8_t *prod = mem, *ws1 = prod + n * pt, *local = ws1 + wsb_local, *all = local + pt, *ws2 = all + (size_t)(ranks > 1 ? ranks : 1) * pt;
+    int rc = GPBC_OK;
+    if (n) rc = scalar_mul_dev(g2, d_bases, n, d_scalars, n, prod, stream);
+    uint8_t *local_out = ranks > 1 ? local : (uint8_t *)d_out;
+    if (rc == GPBC_OK) rc = sum_dev(g2, prod, n, local_out, ws1, wsb_local, stream);
+    if (rc == GPBC_OK && ranks > 1) {
+        rc = comm_allgather(local, pt, all, st);
+        if (rc == GPBC_OK) rc = sum_dev(g2, all, (size_t)ranks, d_out, ws2, wsb_all, stream);
+    }
+    (void)hipFreeAsync(mem, st);
+    return rc;
+}
+int gpbc_g1_scalar_mul_sum_dev(const void *b, const void *s, size_t n, void *o, void *st) { return scalar_mul_sum_dev(false, b, s, n, o, st); }
+int gpbc_g2_scalar_mul_sum_dev(const void *b, const void *s, size_t n, void *o, void *st) { return scalar_mul_sum_dev(true, b, s, n, o, st); }
 int gpbc_g1_sum(const void *p, size_t n, void *o) { return sum_host(false, p, n, o); }
 int gpbc_g2_sum(const void *p, size_t n, void *o) { return sum_host(true, p, n, o); }
 
@@ -272,7 +392,7 @@ int gpbc_fixed_base_create_dev(int is_g2, const void *d_bases, size_t nbase, voi
     if (!nbase || !d_bases) return fail(GPBC_ERR_INVALID_ARG, "fixed-base table needs at least one base");
     TRY(bind_device());
     hipStream_t st = (hipStream_t)stream;
-    gpbc_fixed_base *h = new gpbc_fixed_base{g_device.load(), is_g2 ? 1 : 0, nbase, nullptr, nullptr};
+    gpbc_fixed_base *h = new gpbc_fixed_base{current_device(), is_g2 ? 1 : 0, nbase, nullptr, nullptr};
     hipError_t e1 = hipMalloc((void **)&h->table, fb_table_bytes(nbase, is_g2));
     hipError_t e2 = e1 == hipSuccess ? hipMalloc((void **)&h->base_inf, nbase) : e1;
     if (e1 != hipSuccess || e2 != hipSuccess) {
@@ -342,7 +462,7 @@ int gpbc_fixed_base_msm_dev(const gpbc_fixed_base *h, const void *d_scalars, siz
     if (!n_msm) return GPBC_OK;
     if (!d_scalars || !d_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
     TRY(bind_device());
-    if (g_device.load() != h->device) return fail(GPBC_ERR_INVALID_ARG, "table was built on device %d", h->device);
+    if (current_device() != h->device) return fail(GPBC_ERR_INVALID_ARG, "table was built on device %d", h->device);
     size_t C, n_chunks;
     fb_shape(h, n_msm, &C, &n_chunks);
     if (n_chunks > 1 && (!d_workspace || workspace_bytes < gpbc_fixed_base_msm_workspace_bytes(h, n_msm))) return fail(GPBC_ERR_WORKSPACE, "workspace too small");

@@ -284,9 +284,10 @@ int gpbc_gt_mul_batch_dev(const void *a, const void *b, size_t n, void *o, void 
 int gpbc_gt_div_batch_dev(const void *a, const void *b, size_t n, void *o, void *s) { return gt_binary_dev(1, a, b, n, o, s); }
 int gpbc_gt_inverse_batch_dev(const void *a, size_t n, void *o, void *s) { return gt_binary_dev(2, a, nullptr, n, o, s); }
 
-int gpbc_miller_loop(const void *P, const void *Q, size_t n, void *f_out) {
-    if (!n) return GPBC_OK;
-    if (!P || !Q || !f_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+// Host-pointer entries: [0, n) is split over the bound devices (run_sharded, gpbc_core.hip); each shard uploads, computes and
+// downloads on its own device from its own host thread.
+constexpr size_t SHARD_MIN_UNITS = 4096;
+static int miller_loop_one(const void *P, const void *Q, size_t n, void *f_out) {
     TRY(bind_device());
     DevBuf dP, dQ, dF;
     TRY(dP.upload(P, n * GPBC_G1_BYTES)); TRY(dQ.upload(Q, n * GPBC_G2_BYTES)); TRY(dF.alloc(n * GPBC_GT_BYTES));
@@ -294,9 +295,14 @@ int gpbc_miller_loop(const void *P, const void *Q, size_t n, void *f_out) {
     TRY(sync_default());
     return dF.download(f_out, n * GPBC_GT_BYTES);
 }
-int gpbc_final_exp(const void *f, size_t n, void *gt_out) {
+int gpbc_miller_loop(const void *P, const void *Q, size_t n, void *f_out) {
     if (!n) return GPBC_OK;
-    if (!f || !gt_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    if (!P || !Q || !f_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    return run_sharded(n, SHARD_MIN_UNITS, [=](size_t lo, size_t hi) {
+        return miller_loop_one((const uint8_t *)P + lo * GPBC_G1_BYTES, (const uint8_t *)Q + lo * GPBC_G2_BYTES, hi - lo, (uint8_t *)f_out + lo * GPBC_GT_BYTES);
+    });
+}
+static int final_exp_one(const void *f, size_t n, void *gt_out) {
     TRY(bind_device());
     DevBuf dF;
     TRY(dF.upload(f, n * GPBC_GT_BYTES));
@@ -304,15 +310,27 @@ int gpbc_final_exp(const void *f, size_t n, void *gt_out) {
     TRY(sync_default());
     return dF.download(gt_out, n * GPBC_GT_BYTES);
 }
-int gpbc_pair_batch(const void *P, const void *Q, size_t n, void *gt_out) {
-    if (!n) return fail(GPBC_ERR_INVALID_ARG, "invalid inputs sizes");
-    if (!P || !Q || !gt_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+int gpbc_final_exp(const void *f, size_t n, void *gt_out) {
+    if (!n) return GPBC_OK;
+    if (!f || !gt_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    return run_sharded(n, SHARD_MIN_UNITS, [=](size_t lo, size_t hi) {
+        return final_exp_one((const uint8_t *)f + lo * GPBC_GT_BYTES, hi - lo, (uint8_t *)gt_out + lo * GPBC_GT_BYTES);
+    });
+}
+static int pair_batch_one(const void *P, const void *Q, size_t n, void *gt_out) {
     TRY(bind_device());
     DevBuf dP, dQ, dG;
     TRY(dP.upload(P, n * GPBC_G1_BYTES)); TRY(dQ.upload(Q, n * GPBC_G2_BYTES)); TRY(dG.alloc(n * GPBC_GT_BYTES));
     TRY(gpbc_pair_batch_dev(dP.p, dQ.p, n, dG.p, nullptr));
     TRY(sync_default());
     return dG.download(gt_out, n * GPBC_GT_BYTES);
+}
+int gpbc_pair_batch(const void *P, const void *Q, size_t n, void *gt_out) {
+    if (!n) return fail(GPBC_ERR_INVALID_ARG, "invalid inputs sizes");
+    if (!P || !Q || !gt_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    return run_sharded(n, SHARD_MIN_UNITS, [=](size_t lo, size_t hi) {
+        return pair_batch_one((const uint8_t *)P + lo * GPBC_G1_BYTES, (const uint8_t *)Q + lo * GPBC_G2_BYTES, hi - lo, (uint8_t *)gt_out + lo * GPBC_GT_BYTES);
+    });
 }
 static int check_segments(const uint64_t *seg_off, size_t k, size_t *n_pairs) {
     if (!seg_off) return fail(GPBC_ERR_INVALID_ARG, "null segment table");
@@ -432,14 +450,21 @@ int gpbc_multi_pair_fixed_q_dev(const void *dP, const void *dQ, size_t m, size_t
     HIP_TRY(hipStreamSynchronize(st));
     return GPBC_OK;
 }
-int gpbc_multi_pair_fixed_q(const void *P, const void *Q, size_t m, size_t k, void *gt_out) {
-    if (!k || !m) return fail(GPBC_ERR_INVALID_ARG, "invalid inputs sizes");
-    if (!P || !Q || !gt_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+static int multi_pair_fixed_q_one(const void *P, const void *Q, size_t m, size_t k, void *gt_out) {
     TRY(bind_device());
     DevBuf dP, dQ, dG;
     TRY(dP.upload(P, m * k * GPBC_G1_BYTES)); TRY(dQ.upload(Q, m * GPBC_G2_BYTES)); TRY(dG.alloc(k * GPBC_GT_BYTES));
     TRY(gpbc_multi_pair_fixed_q_dev(dP.p, dQ.p, m, k, dG.p, nullptr));
     return dG.download(gt_out, k * GPBC_GT_BYTES);
+}
+int gpbc_multi_pair_fixed_q(const void *P, const void *Q, size_t m, size_t k, void *gt_out) {
+    if (!k || !m) return fail(GPBC_ERR_INVALID_ARG, "invalid inputs sizes");
+    if (!P || !Q || !gt_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    // segments are the independent units; every device computes the lines of the shared Q list for itself
+    const size_t min_seg = (SHARD_MIN_UNITS + m - 1) / m;
+    return run_sharded(k, min_seg, [=](size_t lo, size_t hi) {
+        return multi_pair_fixed_q_one((const uint8_t *)P + lo * m * GPBC_G1_BYTES, Q, m, hi - lo, (uint8_t *)gt_out + lo * GPBC_GT_BYTES);
+    });
 }
 int gpbc_multi_pair_hostseg_dev(const void *dP, const void *dQ, const uint64_t *seg_off, size_t k, void *d_gt_out, void *stream) {
     if (!k) return fail(GPBC_ERR_INVALID_ARG, "invalid inputs sizes");
@@ -449,11 +474,7 @@ int gpbc_multi_pair_hostseg_dev(const void *dP, const void *dQ, const uint64_t *
     TRY(bind_device());
     return multi_pair_core((const uint8_t *)dP, (const uint8_t *)dQ, seg_off, k, n_pairs, (uint8_t *)d_gt_out, nullptr, (hipStream_t)stream);
 }
-static int multi_pair_host(const void *P, const void *Q, const uint64_t *seg_off, size_t k, void *gt_out, uint8_t *ok_out) {
-    if (!k) return fail(GPBC_ERR_INVALID_ARG, "invalid inputs sizes");
-    size_t n_pairs = 0;
-    TRY(check_segments(seg_off, k, &n_pairs));
-    if ((n_pairs && (!P || !Q)) || (!gt_out && !ok_out)) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+static int multi_pair_host_one(const void *P, const void *Q, const uint64_t *seg_off, size_t k, size_t n_pairs, void *gt_out, uint8_t *ok_out) {
     TRY(bind_device());
     DevBuf dP, dQ, dG, dOk;
     TRY(dP.upload(P, n_pairs * GPBC_G1_BYTES)); TRY(dQ.upload(Q, n_pairs * GPBC_G2_BYTES));
@@ -464,6 +485,22 @@ static int multi_pair_host(const void *P, const void *Q, const uint64_t *seg_off
     if (ok_out) TRY(dOk.download(ok_out, k));
     return GPBC_OK;
 }
+static int multi_pair_host(const void *P, const void *Q, const uint64_t *seg_off, size_t k, void *gt_out, uint8_t *ok_out) {
+    if (!k) return fail(GPBC_ERR_INVALID_ARG, "invalid inputs sizes");
+    size_t n_pairs = 0;
+    TRY(check_segments(seg_off, k, &n_pairs));
+    if ((n_pairs && (!P || !Q)) || (!gt_out && !ok_out)) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    // segments are the independent units: a shard is a run of whole segments with its table rebased to zero
+    const size_t avg = n_pairs / k ? n_pairs / k : 1;
+    return run_sharded(k, (SHARD_MIN_UNITS + avg - 1) / avg, [=](size_t lo, size_t hi) {
+        if (lo == 0 && hi == k) return multi_pair_host_one(P, Q, seg_off, k, n_pairs, gt_out, ok_out);
+        std::vector<uint64_t> sub(hi - lo + 1);
+        const uint64_t base = seg_off[lo];
+        for (size_t j = lo; j <= hi; j++) sub[j - lo] = seg_off[j] - base;
+        return multi_pair_host_one((const uint8_t *)P + base * GPBC_G1_BYTES, (const uint8_t *)Q + base * GPBC_G2_BYTES, sub.data(), hi - lo,
+                                   (size_t)sub.back(), gt_out ? (uint8_t *)gt_out + lo * GPBC_GT_BYTES : nullptr, ok_out ? ok_out + lo : nullptr);
+    });
+}
 int gpbc_multi_pair(const void *P, const void *Q, const uint64_t *seg_off, size_t k, void *gt_out) {
     if (!gt_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
     return multi_pair_host(P, Q, seg_off, k, gt_out, nullptr);
@@ -472,9 +509,7 @@ int gpbc_pairing_check(const void *P, const void *Q, const uint64_t *seg_off, si
     if (!ok_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
     return multi_pair_host(P, Q, seg_off, k, nullptr, ok_out);
 }
-int gpbc_gt_exp_batch(const void *x, const void *k, size_t n, void *out) {
-    if (!n) return GPBC_OK;
-    if (!x || !k || !out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+static int gt_exp_one(const void *x, const void *k, size_t n, void *out) {
     TRY(bind_device());
     DevBuf dX, dK, dO;
     TRY(dX.upload(x, n * GPBC_GT_BYTES)); TRY(dK.upload(k, n * GPBC_SCALAR_BYTES)); TRY(dO.alloc(n * GPBC_GT_BYTES));
@@ -482,9 +517,14 @@ int gpbc_gt_exp_batch(const void *x, const void *k, size_t n, void *out) {
     TRY(sync_default());
     return dO.download(out, n * GPBC_GT_BYTES);
 }
-static int gt_binary_host(int op, const void *a, const void *b, size_t n, void *out) {
+int gpbc_gt_exp_batch(const void *x, const void *k, size_t n, void *out) {
     if (!n) return GPBC_OK;
-    if (!a || (op != 2 && !b) || !out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    if (!x || !k || !out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    return run_sharded(n, SHARD_MIN_UNITS, [=](size_t lo, size_t hi) {
+        return gt_exp_one((const uint8_t *)x + lo * GPBC_GT_BYTES, (const uint8_t *)k + lo * GPBC_SCALAR_BYTES, hi - lo, (uint8_t *)out + lo * GPBC_GT_BYTES);
+    });
+}
+static int gt_binary_one(int op, const void *a, const void *b, size_t n, void *out) {
     TRY(bind_device());
     DevBuf dA, dB, dO;
     TRY(dA.upload(a, n * GPBC_GT_BYTES));
@@ -493,6 +533,13 @@ static int gt_binary_host(int op, const void *a, const void *b, size_t n, void *
     TRY(gt_binary_dev(op, dA.p, dB.p, n, dO.p, nullptr));
     TRY(sync_default());
     return dO.download(out, n * GPBC_GT_BYTES);
+}
+static int gt_binary_host(int op, const void *a, const void *b, size_t n, void *out) {
+    if (!n) return GPBC_OK;
+    if (!a || (op != 2 && !b) || !out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    return run_sharded(n, 4 * SHARD_MIN_UNITS, [=](size_t lo, size_t hi) {
+        return gt_binary_one(op, (const uint8_t *)a + lo * GPBC_GT_BYTES, b ? (const uint8_t *)b + lo * GPBC_GT_BYTES : nullptr, hi - lo, (uint8_t *)out + lo * GPBC_GT_BYTES);
+    });
 }
 int gpbc_gt_mul_batch(const void *a, const void *b, size_t n, void *o) { return gt_binary_host(0, a, b, n, o); }
 int gpbc_gt_div_batch(const void *a, const void *b, size_t n, void *o) { return gt_binary_host(1, a, b, n, o); }

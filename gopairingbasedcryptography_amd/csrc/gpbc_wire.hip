@@ -87,9 +87,7 @@ static int unmarshal_dev(int kind, const void *d_in, size_t elem_bytes, size_t n
     else k_gt_decode<<<grid_for(n), BLOCK, 0, st>>>((const uint8_t *)d_in, (uint8_t *)d_out, d_ok, n);
     return check_launch("wire decode");
 }
-static int marshal_host(int kind, const void *in, size_t n, int compressed, void *out) {
-    if (!n) return GPBC_OK;
-    if (!in || !out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+static int marshal_one(int kind, const void *in, size_t n, int compressed, void *out) {
     TRY(bind_device());
     DevBuf dI, dO;
     TRY(dI.upload(in, n * wire_mem_bytes(kind))); TRY(dO.alloc(n * wire_enc_bytes(kind, compressed)));
@@ -97,8 +95,17 @@ static int marshal_host(int kind, const void *in, size_t n, int compressed, void
     TRY(sync_default());
     return dO.download(out, n * wire_enc_bytes(kind, compressed));
 }
-static int unmarshal_host(int kind, const void *in, size_t elem_bytes, size_t n, void *out, uint8_t *ok) {
-    if (n && (!in || !out || !ok)) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+// host-pointer entries shard [0, n) over the bound devices (run_sharded, gpbc_core.hip)
+constexpr size_t WIRE_SHARD_MIN = 65536;
+static int marshal_host(int kind, const void *in, size_t n, int compressed, void *out) {
+    if (!n) return GPBC_OK;
+    if (!in || !out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    const size_t mb = wire_mem_bytes(kind), eb = wire_enc_bytes(kind, compressed);
+    return run_sharded(n, WIRE_SHARD_MIN, [=](size_t lo, size_t hi) {
+        return marshal_one(kind, (const uint8_t *)in + lo * mb, hi - lo, compressed, (uint8_t *)out + lo * eb);
+    });
+}
+static int unmarshal_one(int kind, const void *in, size_t elem_bytes, size_t n, void *out, uint8_t *ok) {
     DevBuf dI, dO, dK;
     if (n) {
         TRY(bind_device());
@@ -109,6 +116,13 @@ static int unmarshal_host(int kind, const void *in, size_t elem_bytes, size_t n,
     TRY(sync_default());
     TRY(dO.download(out, n * wire_mem_bytes(kind)));
     return dK.download(ok, n);
+}
+static int unmarshal_host(int kind, const void *in, size_t elem_bytes, size_t n, void *out, uint8_t *ok) {
+    if (n && (!in || !out || !ok)) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    const size_t mb = wire_mem_bytes(kind);
+    return run_sharded(n, kind == 1 ? 8192 : WIRE_SHARD_MIN, [=](size_t lo, size_t hi) {      // G2 decoding carries the subgroup check
+        return unmarshal_one(kind, n ? (const uint8_t *)in + lo * elem_bytes : nullptr, elem_bytes, hi - lo, n ? (uint8_t *)out + lo * mb : nullptr, n ? ok + lo : nullptr);
+    });
 }
 int gpbc_g1_marshal_batch(const void *p, size_t n, int c, void *o) { return marshal_host(0, p, n, c != 0, o); }
 int gpbc_g2_marshal_batch(const void *p, size_t n, int c, void *o) { return marshal_host(1, p, n, c != 0, o); }
@@ -132,9 +146,7 @@ static int map_fields_dev(bool g2, const void *d_u, size_t n, void *d_out, void 
     else k_g1_map_fields<<<grid_for(n), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_u, (uint8_t *)d_out, n);
     return check_launch(g2 ? "k_g2_map_fields" : "k_g1_map_fields");
 }
-static int map_fields_host(bool g2, const void *u, size_t n, void *out) {
-    if (!n) return GPBC_OK;
-    if (!u || !out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+static int map_fields_one(bool g2, const void *u, size_t n, void *out) {
     TRY(bind_device());
     size_t pt = g2 ? GPBC_G2_BYTES : GPBC_G1_BYTES;               // two field elements occupy as many bytes as one point
     DevBuf dU, dO;
@@ -142,6 +154,12 @@ static int map_fields_host(bool g2, const void *u, size_t n, void *out) {
     TRY(map_fields_dev(g2, dU.p, n, dO.p, nullptr));
     TRY(sync_default());
     return dO.download(out, n * pt);
+}
+static int map_fields_host(bool g2, const void *u, size_t n, void *out) {
+    if (!n) return GPBC_OK;
+    if (!u || !out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    const size_t pt = g2 ? GPBC_G2_BYTES : GPBC_G1_BYTES;
+    return run_sharded(n, 8192, [=](size_t lo, size_t hi) { return map_fields_one(g2, (const uint8_t *)u + lo * pt, hi - lo, (uint8_t *)out + lo * pt); });
 }
 int gpbc_g1_map_to_curve_batch(const void *u, size_t n, void *o) { return map_fields_host(false, u, n, o); }
 int gpbc_g2_map_to_curve_batch(const void *u, size_t n, void *o) { return map_fields_host(true, u, n, o); }

@@ -29,10 +29,23 @@ def _rank():
     return dist.get_rank() if dist.is_initialized() else 0
 
 
-def all_gather_rows(local, n_total, device=None):
+def init_library_comm(engine):
+    """Give the engine's C library its own RCCL communicator spanning the torch.distributed job (one process per GPU): rank 0
+    draws the id, torch.distributed carries the 128 bytes, every rank joins with its bound device.  Afterwards
+    engine.allgather / engine.g1_scalar_mul_sum run their collective inside the library (ncclAllGather on bytes over xGMI)."""
+    world, rank = _world(), _rank()
+    ident = [engine.comm_unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(ident, src=0)
+    engine.comm_init_rank(ident[0], world, rank)
+
+
+def all_gather_rows(local, n_total, device=None, engine=None):
     """All-gather row blocks of a uint8 [n_local, width] array whose sizes follow shard_range(n_total, ...).
 
-    One collective on a padded byte buffer (ncclAllGather on uint8 over xGMI on the GPU box)."""
+    One collective on a padded byte buffer: ncclAllGather on uint8 over xGMI — through the engine's own communicator when it
+    has one (`engine.comm_ranks() == world`, see init_library_comm), through torch.distributed otherwise (gloo in the CPU
+    tests)."""
     world = _world()
     t = torch.as_tensor(np.ascontiguousarray(local)) if not isinstance(local, torch.Tensor) else local
     if world == 1:
@@ -43,8 +56,11 @@ def all_gather_rows(local, n_total, device=None):
     max_rows = (n_total + world - 1) // world
     pad = torch.zeros((max_rows, width), dtype=torch.uint8, device=t.device)
     pad[: t.shape[0]] = t
-    out = torch.empty((world * max_rows, width), dtype=torch.uint8, device=t.device)
-    dist.all_gather_into_tensor(out, pad)
+    if engine is not None and t.is_cuda and getattr(engine, "comm_ranks", lambda: 0)() == world:
+        out = engine.allgather(pad.reshape(-1)).reshape(world * max_rows, width)
+    else:
+        out = torch.empty((world * max_rows, width), dtype=torch.uint8, device=t.device)
+        dist.all_gather_into_tensor(out, pad)
     rows = []
     for r in range(world):
         lo, hi = shard_range(n_total, r, world)
@@ -55,7 +71,7 @@ def all_gather_rows(local, n_total, device=None):
 def pair_batch_gather(engine, P_local, Q_local, n_total, device=None):
     """Config 5 shape: every rank pairs its own shard, then all ranks receive all n_total GT values."""
     gt = engine.pair_batch(P_local, Q_local)
-    return all_gather_rows(gt, n_total, device=device)
+    return all_gather_rows(gt, n_total, device=device, engine=engine)
 
 
 def aggregate_verify(engine, pk_local, rho_local, sigma_local, H, g1, neg, device=None):

@@ -1,0 +1,427 @@
+// Package gpbcbn254 mirrors the gnark-crypto bn254 calls used by mmsyan/GoPairingBasedCryptography and runs them on
+// MI355X GPUs through the C ABI of libgpbc_bn254.so (include/gpbc_bn254.h).
+//
+// gnark's in-memory structs are the ABI buffers: fp.Element is [4]uint64 Montgomery little-endian, so a
+// []bn254.G1Affine is already the 64-byte-stride array the library reads (unsafe.SliceData) and results land directly
+// in bn254.GT / G1Affine / G2Affine values.  There is one code path: no call falls back to gnark's CPU arithmetic.
+//
+// NOT COMPILED in the build image of this repository (no Go toolchain there); the same surface is compiled and tested
+// as C++ (include/gpbc_bn254.hpp, tests/cpp/*.cpp) and as Python ctypes (gopairingbasedcryptography_amd/bn254.py).
+// INTEGRATION.md maps every function to the reference call sites it replaces.
+package gpbcbn254
+
+/*
+#cgo CFLAGS: -I${SRCDIR}/../include
+#cgo LDFLAGS: -L${SRCDIR}/../gopairingbasedcryptography_amd -lgpbc_bn254 -Wl,-rpath,${SRCDIR}/../gopairingbasedcryptography_amd
+#include "gpbc_bn254.h"
+*/
+import "C"
+
+import (
+	"errors"
+	"math/big"
+	"unsafe"
+
+	"github.com/consensys/gnark-crypto/ecc/bn254"
+	"github.com/consensys/gnark-crypto/ecc/bn254/fp"
+	"github.com/consensys/gnark-crypto/ecc/bn254/fr"
+)
+
+var errSizes = errors.New("invalid inputs sizes") // gnark's own error text for Pair / PairingCheck
+
+func status(rc C.int) error {
+	if rc == 0 {
+		return nil
+	}
+	return errors.New(C.GoString(C.gpbc_last_error()))
+}
+
+func must(rc C.int) {
+	if rc != 0 {
+		panic("gpbcbn254: " + C.GoString(C.gpbc_last_error())) // gnark's methods cannot fail: surface engine errors loudly
+	}
+}
+
+// Init binds the process to the given HIP devices (nil or empty: every visible device).  Host-slice batch calls then
+// shard their index range over all of them inside the library; results do not depend on the number of devices.
+func Init(devices []int) error {
+	if len(devices) == 0 {
+		n := int(C.gpbc_device_count())
+		if n <= 0 {
+			return errors.New(C.GoString(C.gpbc_last_error()))
+		}
+		for i := 0; i < n; i++ {
+			devices = append(devices, i)
+		}
+	}
+	d := make([]C.int, len(devices))
+	for i, v := range devices {
+		d[i] = C.int(v)
+	}
+	return status(C.gpbc_init_devices(&d[0], C.int(len(d))))
+}
+
+// NumDevices is the number of GPUs bound by Init.
+func NumDevices() int { return int(C.gpbc_num_devices()) }
+
+// InitCollectives opens one RCCL communicator over the bound devices: the partial sums of G1ScalarMulSum / G2ScalarMulSum
+// are then exchanged by ncclAllGather over xGMI instead of through the host.
+func InitCollectives() error { return status(C.gpbc_comm_init_all()) }
+
+// Shutdown releases the library's device memory and communicators.
+func Shutdown() error { return status(C.gpbc_shutdown()) }
+
+// Pair replaces bn254.Pair (cpabe/bsw07/bsw07_cpabe.go:75,184; access/tree/access_tree_node.go:106,110,119;
+// bibe/afp25_bibe/afp25_bibe.go:227,395,399,403; ...): product of pairings, one final exponentiation.
+func Pair(P []bn254.G1Affine, Q []bn254.G2Affine) (bn254.GT, error) {
+	var gt bn254.GT
+	if len(P) == 0 || len(P) != len(Q) {
+		return gt, errSizes
+	}
+	seg := [2]C.uint64_t{0, C.uint64_t(len(P))}
+	rc := C.gpbc_multi_pair(unsafe.Pointer(unsafe.SliceData(P)), unsafe.Pointer(unsafe.SliceData(Q)),
+		&seg[0], 1, unsafe.Pointer(&gt))
+	return gt, status(rc)
+}
+
+// PairingCheck replaces bn254.PairingCheck (signature/bls01_signature/bls_signature.go:81).
+func PairingCheck(P []bn254.G1Affine, Q []bn254.G2Affine) (bool, error) {
+	if len(P) == 0 || len(P) != len(Q) {
+		return false, errSizes
+	}
+	seg := [2]C.uint64_t{0, C.uint64_t(len(P))}
+	var ok C.uint8_t
+	rc := C.gpbc_pairing_check(unsafe.Pointer(unsafe.SliceData(P)), unsafe.Pointer(unsafe.SliceData(Q)), &seg[0], 1, &ok)
+	return ok == 1, status(rc)
+}
+
+// PairBatch is the batched form the engine adds: out[i] = Pair([P[i]], [Q[i]]).
+func PairBatch(P []bn254.G1Affine, Q []bn254.G2Affine) ([]bn254.GT, error) {
+	if len(P) == 0 || len(P) != len(Q) {
+		return nil, errSizes
+	}
+	out := make([]bn254.GT, len(P))
+	rc := C.gpbc_pair_batch(unsafe.Pointer(unsafe.SliceData(P)), unsafe.Pointer(unsafe.SliceData(Q)),
+		C.size_t(len(P)), unsafe.Pointer(unsafe.SliceData(out)))
+	return out, status(rc)
+}
+
+// MultiPair: out[j] = Pair(P[segOff[j]:segOff[j+1]], Q[segOff[j]:segOff[j+1]]) — the products the reference assembles
+// from single pairings, GT.Mul / Div / Exp (ibe/bb04_ibe/bb04_ibe.go:213-225, access/tree/access_tree_node.go:106-157,
+// bibe/afp25_bibe/afp25_bibe.go:395-413) with one final exponentiation per segment.
+func MultiPair(P []bn254.G1Affine, Q []bn254.G2Affine, segOff []uint64) ([]bn254.GT, error) {
+	if len(segOff) < 2 || len(P) != len(Q) || segOff[len(segOff)-1] != uint64(len(P)) {
+		return nil, errSizes
+	}
+	out := make([]bn254.GT, len(segOff)-1)
+	var p, q unsafe.Pointer
+	if len(P) > 0 {
+		p, q = unsafe.Pointer(unsafe.SliceData(P)), unsafe.Pointer(unsafe.SliceData(Q))
+	}
+	rc := C.gpbc_multi_pair(p, q, (*C.uint64_t)(unsafe.SliceData(segOff)), C.size_t(len(out)), unsafe.Pointer(unsafe.SliceData(out)))
+	return out, status(rc)
+}
+
+// PairFixedQ: out[j] = Pair(P[j*m:(j+1)*m], Q) for one shared list Q of m points (a BSW07 key against many ciphertexts:
+// access/tree/access_tree_node.go:106-119 under cpabe/bsw07/bsw07_cpabe.go:172-195; gnark: PrecomputeLines).
+func PairFixedQ(P []bn254.G1Affine, Q []bn254.G2Affine) ([]bn254.GT, error) {
+	if len(Q) == 0 || len(P) == 0 || len(P)%len(Q) != 0 {
+		return nil, errSizes
+	}
+	out := make([]bn254.GT, len(P)/len(Q))
+	rc := C.gpbc_multi_pair_fixed_q(unsafe.Pointer(unsafe.SliceData(P)), unsafe.Pointer(unsafe.SliceData(Q)),
+		C.size_t(len(Q)), C.size_t(len(out)), unsafe.Pointer(unsafe.SliceData(out)))
+	return out, status(rc)
+}
+
+// scalarBytes: big.Int -> 32-byte little-endian, reduced mod r (call sites pass fr.Element.BigInt values or rand.Int(r)).
+func scalarBytes(s *big.Int, dst *[32]byte) {
+	var t big.Int
+	t.Mod(s, fr.Modulus())
+	b := t.Bytes() // big-endian, at most 32 bytes after the reduction
+	for i := range b {
+		dst[len(b)-1-i] = b[i]
+	}
+}
+
+// G1ScalarMultiplication replaces new(bn254.G1Affine).ScalarMultiplication(a, s)
+// (signature/bls01_signature/bls_signature.go:45; cpabe/bsw07/bsw07_cpabe.go:69,149,157,160).
+func G1ScalarMultiplication(p, a *bn254.G1Affine, s *big.Int) *bn254.G1Affine {
+	var k [32]byte
+	scalarBytes(s, &k)
+	var out bn254.G1Affine // a and p may alias
+	must(C.gpbc_g1_scalar_mul_batch(unsafe.Pointer(a), 1, unsafe.Pointer(&k[0]), 1, unsafe.Pointer(&out)))
+	*p = out
+	return p
+}
+
+// G1ScalarMultiplicationBase replaces new(bn254.G1Affine).ScalarMultiplicationBase(s).
+func G1ScalarMultiplicationBase(p *bn254.G1Affine, s *big.Int) *bn254.G1Affine {
+	_, _, g1, _ := bn254.Generators()
+	return G1ScalarMultiplication(p, &g1, s)
+}
+
+// G2ScalarMultiplication replaces new(bn254.G2Affine).ScalarMultiplication(a, s)
+// (signature/bls01_signature/bls_signature.go:63; cpabe/bsw07/bsw07_cpabe.go:73,83,103-121).
+func G2ScalarMultiplication(p, a *bn254.G2Affine, s *big.Int) *bn254.G2Affine {
+	var k [32]byte
+	scalarBytes(s, &k)
+	var out bn254.G2Affine
+	must(C.gpbc_g2_scalar_mul_batch(unsafe.Pointer(a), 1, unsafe.Pointer(&k[0]), 1, unsafe.Pointer(&out)))
+	*p = out
+	return p
+}
+
+// G2ScalarMultiplicationBase replaces new(bn254.G2Affine).ScalarMultiplicationBase(s).
+func G2ScalarMultiplicationBase(p *bn254.G2Affine, s *big.Int) *bn254.G2Affine {
+	_, _, _, g2 := bn254.Generators()
+	return G2ScalarMultiplication(p, &g2, s)
+}
+
+func frBytes(s []fr.Element) [][32]byte {
+	k := make([][32]byte, len(s))
+	for i := range s {
+		var b big.Int
+		scalarBytes(s[i].BigInt(&b), &k[i])
+	}
+	return k
+}
+
+// G1ScalarMultiplicationBatch: out[i] = [s[i]] bases[i]  (len(bases) == 1 shares the base, e.g. ScalarMultiplicationBase).
+func G1ScalarMultiplicationBatch(bases []bn254.G1Affine, s []fr.Element) ([]bn254.G1Affine, error) {
+	if len(s) == 0 {
+		return nil, nil
+	}
+	if len(bases) != 1 && len(bases) != len(s) {
+		return nil, errSizes
+	}
+	k := frBytes(s)
+	out := make([]bn254.G1Affine, len(s))
+	rc := C.gpbc_g1_scalar_mul_batch(unsafe.Pointer(unsafe.SliceData(bases)), C.size_t(len(bases)),
+		unsafe.Pointer(unsafe.SliceData(k)), C.size_t(len(s)), unsafe.Pointer(unsafe.SliceData(out)))
+	return out, status(rc)
+}
+
+// G2ScalarMultiplicationBatch: the same over G2.
+func G2ScalarMultiplicationBatch(bases []bn254.G2Affine, s []fr.Element) ([]bn254.G2Affine, error) {
+	if len(s) == 0 {
+		return nil, nil
+	}
+	if len(bases) != 1 && len(bases) != len(s) {
+		return nil, errSizes
+	}
+	k := frBytes(s)
+	out := make([]bn254.G2Affine, len(s))
+	rc := C.gpbc_g2_scalar_mul_batch(unsafe.Pointer(unsafe.SliceData(bases)), C.size_t(len(bases)),
+		unsafe.Pointer(unsafe.SliceData(k)), C.size_t(len(s)), unsafe.Pointer(unsafe.SliceData(out)))
+	return out, status(rc)
+}
+
+// G1ScalarMulSum = sum_i [s[i]] bases[i]: the verifier's side of BLS aggregate verification with random linear
+// combination (a loop of ScalarMultiplication + Add in the reference's style, gka/agka09/asbb.go:193-220), sharded over
+// all bound GPUs with the partial sums combined inside the library.
+func G1ScalarMulSum(bases []bn254.G1Affine, s []fr.Element) (bn254.G1Affine, error) {
+	var out bn254.G1Affine
+	if len(bases) != len(s) {
+		return out, errSizes
+	}
+	if len(s) == 0 {
+		return out, nil
+	}
+	k := frBytes(s)
+	rc := C.gpbc_g1_scalar_mul_sum(unsafe.Pointer(unsafe.SliceData(bases)), unsafe.Pointer(unsafe.SliceData(k)), C.size_t(len(s)), unsafe.Pointer(&out))
+	return out, status(rc)
+}
+
+// G2ScalarMulSum: the same over G2.
+func G2ScalarMulSum(bases []bn254.G2Affine, s []fr.Element) (bn254.G2Affine, error) {
+	var out bn254.G2Affine
+	if len(bases) != len(s) {
+		return out, errSizes
+	}
+	if len(s) == 0 {
+		return out, nil
+	}
+	k := frBytes(s)
+	rc := C.gpbc_g2_scalar_mul_sum(unsafe.Pointer(unsafe.SliceData(bases)), unsafe.Pointer(unsafe.SliceData(k)), C.size_t(len(s)), unsafe.Pointer(&out))
+	return out, status(rc)
+}
+
+// gtExp256: z = x^e for one 32-byte little-endian exponent.
+func gtExp256(x *bn254.GT, e *[32]byte) bn254.GT {
+	var z bn254.GT
+	must(C.gpbc_gt_exp_batch(unsafe.Pointer(x), unsafe.Pointer(&e[0]), 1, unsafe.Pointer(&z)))
+	return z
+}
+
+// GTExp replaces new(bn254.GT).Exp(x, k) (access/tree/access_tree_node.go:123,156; bibe/afp25_bibe/afp25_bibe.go:258-259).
+// Like gnark it takes ANY big.Int and does not reduce it (x need not lie in the order-r subgroup: the reference's
+// SetRandom messages do not): a negative k inverts x first; an exponent wider than the kernel's 256 bits is evaluated in
+// 256-bit digits, x^k = prod_i (x^(2^(256 i)))^(k_i).  The reference's call sites pass values below r: one digit.
+func GTExp(z *bn254.GT, x bn254.GT, k *big.Int) *bn254.GT {
+	var abs big.Int
+	abs.Abs(k)
+	base := x
+	if k.Sign() < 0 {
+		var inv bn254.GT
+		must(C.gpbc_gt_inverse_batch(unsafe.Pointer(&x), 1, unsafe.Pointer(&inv)))
+		base = inv
+	}
+	var acc bn254.GT
+	acc.SetOne()
+	mask := new(big.Int).Sub(new(big.Int).Lsh(big.NewInt(1), 256), big.NewInt(1))
+	var two255, two [32]byte
+	two255[31] = 0x80
+	two[0] = 2
+	for first := true; ; first = false {
+		var digit big.Int
+		digit.And(&abs, mask)
+		var e [32]byte
+		b := digit.Bytes() // at most 32 bytes
+		for i := range b {
+			e[len(b)-1-i] = b[i]
+		}
+		t := gtExp256(&base, &e)
+		if first {
+			acc = t
+		} else {
+			must(C.gpbc_gt_mul_batch(unsafe.Pointer(&acc), unsafe.Pointer(&t), 1, unsafe.Pointer(&acc)))
+		}
+		abs.Rsh(&abs, 256)
+		if abs.Sign() == 0 {
+			break
+		}
+		h := gtExp256(&base, &two255) // base^(2^256) = (base^(2^255))^2
+		base = gtExp256(&h, &two)
+	}
+	*z = acc
+	return z
+}
+
+// GTMul / GTDiv / GTInverse replace (*GT).Mul / Div / Inverse (access/tree/access_tree_node.go:114,157;
+// cpabe/bsw07/bsw07_cpabe.go:189-190).  Batched: one element per index.
+func GTMulBatch(a, b []bn254.GT) ([]bn254.GT, error) {
+	if len(a) != len(b) {
+		return nil, errSizes
+	}
+	out := make([]bn254.GT, len(a))
+	if len(a) == 0 {
+		return out, nil
+	}
+	rc := C.gpbc_gt_mul_batch(unsafe.Pointer(unsafe.SliceData(a)), unsafe.Pointer(unsafe.SliceData(b)), C.size_t(len(a)), unsafe.Pointer(unsafe.SliceData(out)))
+	return out, status(rc)
+}
+func GTDivBatch(a, b []bn254.GT) ([]bn254.GT, error) {
+	if len(a) != len(b) {
+		return nil, errSizes
+	}
+	out := make([]bn254.GT, len(a))
+	if len(a) == 0 {
+		return out, nil
+	}
+	rc := C.gpbc_gt_div_batch(unsafe.Pointer(unsafe.SliceData(a)), unsafe.Pointer(unsafe.SliceData(b)), C.size_t(len(a)), unsafe.Pointer(unsafe.SliceData(out)))
+	return out, status(rc)
+}
+
+// MarshalG1Batch / UnmarshalG1Batch replace element.Marshal() / g1.Unmarshal(data)
+// (serialization/serialization_curve.go:5-7,17-21) n elements per call.  Unlike the reference, the decode error is
+// returned per element, not dropped.
+func MarshalG1Batch(pts []bn254.G1Affine, compressed bool) []byte {
+	w, c := 64, C.int(0)
+	if compressed {
+		w, c = 32, 1
+	}
+	out := make([]byte, w*len(pts))
+	if len(pts) > 0 {
+		must(C.gpbc_g1_marshal_batch(unsafe.Pointer(unsafe.SliceData(pts)), C.size_t(len(pts)), c, unsafe.Pointer(unsafe.SliceData(out))))
+	}
+	return out
+}
+func UnmarshalG1Batch(data []byte, elemBytes int) ([]bn254.G1Affine, []bool, error) {
+	if elemBytes != 32 && elemBytes != 64 {
+		return nil, nil, errors.New("G1 element size must be 32 or 64")
+	}
+	n := len(data) / elemBytes
+	out, ok8, ok := make([]bn254.G1Affine, n), make([]uint8, n), make([]bool, n)
+	if n == 0 {
+		return out, ok, nil
+	}
+	rc := C.gpbc_g1_unmarshal_batch(unsafe.Pointer(unsafe.SliceData(data)), C.size_t(elemBytes), C.size_t(n),
+		unsafe.Pointer(unsafe.SliceData(out)), (*C.uint8_t)(unsafe.SliceData(ok8)))
+	for i := range ok8 {
+		ok[i] = ok8[i] == 1
+	}
+	return out, ok, status(rc)
+}
+func MarshalG2Batch(pts []bn254.G2Affine, compressed bool) []byte {
+	w, c := 128, C.int(0)
+	if compressed {
+		w, c = 64, 1
+	}
+	out := make([]byte, w*len(pts))
+	if len(pts) > 0 {
+		must(C.gpbc_g2_marshal_batch(unsafe.Pointer(unsafe.SliceData(pts)), C.size_t(len(pts)), c, unsafe.Pointer(unsafe.SliceData(out))))
+	}
+	return out
+}
+func UnmarshalG2Batch(data []byte, elemBytes int) ([]bn254.G2Affine, []bool, error) {
+	if elemBytes != 64 && elemBytes != 128 {
+		return nil, nil, errors.New("G2 element size must be 64 or 128")
+	}
+	n := len(data) / elemBytes
+	out, ok8, ok := make([]bn254.G2Affine, n), make([]uint8, n), make([]bool, n)
+	if n == 0 {
+		return out, ok, nil
+	}
+	rc := C.gpbc_g2_unmarshal_batch(unsafe.Pointer(unsafe.SliceData(data)), C.size_t(elemBytes), C.size_t(n),
+		unsafe.Pointer(unsafe.SliceData(out)), (*C.uint8_t)(unsafe.SliceData(ok8)))
+	for i := range ok8 {
+		ok[i] = ok8[i] == 1
+	}
+	return out, ok, status(rc)
+}
+func MarshalGTBatch(gt []bn254.GT) []byte { // GT.Marshal() = GT.Bytes() (hash/hash_from_gt.go:5-8)
+	out := make([]byte, 384*len(gt))
+	if len(gt) > 0 {
+		must(C.gpbc_gt_marshal_batch(unsafe.Pointer(unsafe.SliceData(gt)), C.size_t(len(gt)), unsafe.Pointer(unsafe.SliceData(out))))
+	}
+	return out
+}
+
+// HashToG1Batch replaces bn254.HashToG1(msg, dst) (hash/hash_to.go:113-119,169-175): gnark's own fp.Hash does the
+// byte hashing (expand_message_xmd), the engine both maps, the addition and — G2 — the cofactor clearing.
+func HashToG1Batch(msgs [][]byte, dst []byte) ([]bn254.G1Affine, error) {
+	u := make([]fp.Element, 0, 2*len(msgs))
+	for _, m := range msgs {
+		e, err := fp.Hash(m, dst, 2)
+		if err != nil {
+			return nil, err
+		}
+		u = append(u, e...)
+	}
+	out := make([]bn254.G1Affine, len(msgs))
+	if len(msgs) == 0 {
+		return out, nil
+	}
+	rc := C.gpbc_g1_map_to_curve_batch(unsafe.Pointer(unsafe.SliceData(u)), C.size_t(len(msgs)), unsafe.Pointer(unsafe.SliceData(out)))
+	return out, status(rc)
+}
+
+// HashToG2Batch replaces bn254.HashToG2 (hash/hash_to.go:204-210,271-277): four base-field elements per message,
+// E2 j = elements 2j (A0) and 2j+1 (A1).
+func HashToG2Batch(msgs [][]byte, dst []byte) ([]bn254.G2Affine, error) {
+	u := make([]fp.Element, 0, 4*len(msgs))
+	for _, m := range msgs {
+		e, err := fp.Hash(m, dst, 4)
+		if err != nil {
+			return nil, err
+		}
+		u = append(u, e...)
+	}
+	out := make([]bn254.G2Affine, len(msgs))
+	if len(msgs) == 0 {
+		return out, nil
+	}
+	rc := C.gpbc_g2_map_to_curve_batch(unsafe.Pointer(unsafe.SliceData(u)), C.size_t(len(msgs)), unsafe.Pointer(unsafe.SliceData(out)))
+	return out, status(rc)
+}

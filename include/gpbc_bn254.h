@@ -44,15 +44,50 @@ typedef enum {
     GPBC_ERR_INVALID_ARG = -1,   /* null pointer, n == 0 where gnark errors ("invalid inputs sizes"), bad segment table */
     GPBC_ERR_NO_DEVICE = -2,     /* no HIP device / gpbc_init not successful */
     GPBC_ERR_HIP = -3,           /* a HIP runtime call failed; see gpbc_last_error() */
-    GPBC_ERR_WORKSPACE = -4      /* *_dev call given a workspace smaller than gpbc_*_workspace_bytes() */
+    GPBC_ERR_WORKSPACE = -4,     /* *_dev call given a workspace smaller than gpbc_*_workspace_bytes() */
+    GPBC_ERR_COMM = -5           /* RCCL missing or a collective failed; see gpbc_last_error() */
 } gpbc_status;
 
-/* ---- lifetime --------------------------------------------------------------------------------- */
-int gpbc_init(int device);                 /* bind this process to HIP device `device`; idempotent */
+/* ---- lifetime and devices ----------------------------------------------------------------------
+ * The library is bound to a LIST of HIP devices (SURVEY.md §8b "init(devices)", §8e "one host thread + one stream per
+ * device").  Every host thread has a current device — gpbc_set_device(index into the list), thread-local, default index
+ * 0 — on which its *_dev calls and its un-sharded host calls run, so one Go / C++ process drives all the MI355X of a node:
+ * one thread per device with device-resident buffers, or simply the host-pointer batch entries, which split their index
+ * range [0, n) over all bound devices themselves (contiguous shards, sizes differing by at most one, one internal host
+ * thread per device, no data-path collective) and return when every shard is back in the caller's buffer.  Results do not
+ * depend on the number of devices. */
+int gpbc_init(int device);                 /* = gpbc_init_devices(&device, 1); idempotent */
+int gpbc_init_devices(const int *devices, int n_devices);   /* HIP ordinals, each gfx950; idempotent for an equal list.  An ordinal may
+                                                             * appear twice (a one-GPU rig rehearsing the sharded paths: the slots
+                                                             * then share that GPU); RCCL refuses such a list. */
+int gpbc_num_devices(void);                /* devices bound by init (0 before) */
+int gpbc_device_at(int index);             /* HIP ordinal of bound device `index`, <0 on error */
+int gpbc_set_device(int index);            /* current device of the calling thread */
+int gpbc_get_device(void);                 /* its index, <0 before init */
+int gpbc_set_host_sharding(int on);        /* default 1; 0: host-pointer entries stay on the caller's current device */
 int gpbc_shutdown(void);
 const char *gpbc_last_error(void);         /* thread-local, never NULL */
 int gpbc_device_count(void);               /* number of visible HIP devices, <0 on error */
 int gpbc_abi_version(void);
+
+/* ---- collectives (RCCL over xGMI) --------------------------------------------------------------
+ * The path has exactly one exchange step: an all-gather of byte rows — 192 B of partial sums per rank in
+ * the aggregate-verify path (BASELINE config 3), n/G x 384 B of GT values per rank in batched decryption (config 5).
+ * RCCL is opened with dlopen when a communicator is first requested (an RCCL already loaded in the process, e.g. PyTorch's,
+ * is reused); without it these entries fail with GPBC_ERR_COMM and everything else works.
+ *   one process, all bound devices:   gpbc_comm_init_all()  -> rank = device index, gpbc_allgather_all_dev()
+ *   one process per GPU (torchrun):   rank 0 calls gpbc_comm_get_unique_id(), the launcher broadcasts the 128 bytes, every
+ *                                     process calls gpbc_comm_init_rank(id, n_ranks, rank) -> gpbc_allgather_dev()
+ * recv holds n_ranks blocks of bytes_per_rank in rank order; enqueued on the stream(s), not synchronised. */
+#define GPBC_COMM_ID_BYTES 128
+int gpbc_comm_init_all(void);
+int gpbc_comm_get_unique_id(void *id_out);
+int gpbc_comm_init_rank(const void *id, int n_ranks, int rank);
+int gpbc_comm_ranks(void);                 /* 0 when no communicator exists */
+int gpbc_comm_rank(void);                  /* rank of the calling thread's current device */
+int gpbc_comm_destroy(void);
+int gpbc_allgather_dev(const void *d_send, size_t bytes_per_rank, void *d_recv, void *stream);
+int gpbc_allgather_all_dev(const void *const *d_send, size_t bytes_per_rank, void *const *d_recv, void *const *streams);
 
 /* ---- pairings ----------------------------------------------------------------------------------
  * bn254.Pair(P []G1Affine, Q []G2Affine) (GT, error) with len==1, n times
@@ -118,6 +153,20 @@ int gpbc_g2_sum(const void *pts, size_t n, void *out);
 size_t gpbc_sum_workspace_bytes(size_t n, int is_g2);
 int gpbc_g1_sum_dev(const void *d_pts, size_t n, void *d_out, void *d_workspace, size_t workspace_bytes, void *stream);
 int gpbc_g2_sum_dev(const void *d_pts, size_t n, void *d_out, void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* sum_i [s_i] P_i — the verifier's side of BLS aggregate verification with random linear combination (BASELINE config 3:
+ * A = sum rho_i pk_i in G1, B = sum rho_i sigma_i in G2; signature/bls01_signature/bls_signature.go:71-89 verifies one,
+ * gka/agka09/asbb_test.go:203-238 has the aggregate shape).  nbase == n.
+ * Host form: sharded over the bound devices like every batch entry; each device reduces its shard to one partial sum, and
+ * the partial sums are combined on device 0 — exchanged by ONE RCCL all-gather of a point per rank when
+ * gpbc_comm_init_all() was called, through the host otherwise.
+ * _dev form (one process per GPU): the calling rank's shard in device memory; with a communicator (gpbc_comm_init_rank)
+ * the partial sums of all ranks are all-gathered and added, so every rank ends with the global sum; without one the
+ * result is the local sum.  Stream-ordered, not synchronised. */
+int gpbc_g1_scalar_mul_sum(const void *bases, const void *scalars, size_t n, void *out);
+int gpbc_g2_scalar_mul_sum(const void *bases, const void *scalars, size_t n, void *out);
+int gpbc_g1_scalar_mul_sum_dev(const void *d_bases, const void *d_scalars, size_t n, void *d_out, void *stream);
+int gpbc_g2_scalar_mul_sum_dev(const void *d_bases, const void *d_scalars, size_t n, void *d_out, void *stream);
 
 /* ---- GT arithmetic -----------------------------------------------------------------------------
  * (*GT).Exp(x, k) for k >= 0 (access/tree/access_tree_node.go:123,156; bibe/afp25_bibe/afp25_bibe.go:258-259);

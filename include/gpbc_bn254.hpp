@@ -33,6 +33,19 @@ struct Scalar {
 
 inline void check(int rc) { if (rc < 0) throw std::runtime_error(std::string("gpbc: ") + gpbc_last_error()); }
 inline void Init(int device = 0) { check(gpbc_init(device)); }
+// Bind the process to several MI355X (HIP ordinals): host-pointer batch calls then shard over all of them, and a thread
+// picks the device of its *_dev calls with SetDevice(index).  InitAllDevices() takes every visible device.
+inline void Init(const std::vector<int> &devices) { check(gpbc_init_devices(devices.data(), (int)devices.size())); }
+inline int InitAllDevices() {
+    int n = gpbc_device_count();
+    check(n);
+    std::vector<int> d(n);
+    for (int i = 0; i < n; i++) d[i] = i;
+    Init(d);
+    return n;
+}
+inline int NumDevices() { return gpbc_num_devices(); }
+inline void SetDevice(int index) { check(gpbc_set_device(index)); }
 
 struct fpElement { uint64_t l[4]; };
 struct E2 { fpElement A0, A1; };

@@ -1,0 +1,221 @@
+// ONE host process drives every visible MI355X through the C ABI (include/gpbc_bn254.h; SURVEY.md §8b "init(devices)",
+// §8e "one host thread + one HIP stream per device") — what a Go host calling the cgo shim does:
+//   1. the host-pointer batch entries shard their index range over the bound devices and must return the bits a single
+//      device returns (pairings, ragged multi-pairings, PairingCheck, fixed-Q multi-pairing, G1 / G2 scalar multiplication,
+//      GT.Exp / Mul, wire formats, point sums and the aggregate-verify sums  sum [rho_i] P_i);
+//   2. one thread per device with device-resident buffers and its own stream (gpbc_set_device + *_dev entries);
+//   3. the RCCL all-gather of GT rows and of partial sums over the in-process communicator (gpbc_comm_init_all).
+// With one visible GPU the device list is {0, 0}: two slots share the GPU, so the sharding code (offsets, rebased segment
+// tables, partial sums) still runs; RCCL is then exercised with one rank.
+// build: g++ -std=c++17 -pthread -D__HIP_PLATFORM_AMD__ -I include -I /opt/rocm/include tests/cpp/test_multi_device.cpp
+//        -L gopairingbasedcryptography_amd -lgpbc_bn254 -L /opt/rocm/lib -lamdhip64
+#include <hip/hip_runtime_api.h>
+#include <cstdio>
+#include <cstring>
+#include <thread>
+#include <vector>
+#include "gpbc_bn254.hpp"
+
+using namespace bn254;
+#define EXPECT(c) do { if (!(c)) { printf("FAIL line %d: %s  (%s)\n", __LINE__, #c, gpbc_last_error()); return 1; } } while (0)
+#define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("FAIL line %d: %s: %s\n", __LINE__, #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+template <class T> static bool same(const std::vector<T> &a, const std::vector<T> &b) {
+    return a.size() == b.size() && std::memcmp(a.data(), b.data(), a.size() * sizeof(T)) == 0;
+}
+
+int main() {
+    const int visible = gpbc_device_count();
+    EXPECT(visible >= 1);
+    std::vector<int> devs;
+    for (int i = 0; i < visible; i++) devs.push_back(i);
+    const bool shared_gpu = visible == 1;
+    if (shared_gpu) devs.push_back(0);
+    Init(devs);
+    const int nd = NumDevices();
+    EXPECT(nd == (int)devs.size());
+    for (int i = 0; i < nd; i++) EXPECT(gpbc_device_at(i) == devs[i]);
+    EXPECT(gpbc_set_device(nd) < 0 && gpbc_set_device(-1) < 0);          // out of range: error, current device unchanged
+    EXPECT(gpbc_get_device() == 0);
+    printf("%d visible GPU(s), %d bound slot(s)%s\n", visible, nd, shared_gpu ? " (one GPU listed twice)" : "");
+
+    G1Affine g1; G2Affine g2; Generators(g1, g2);
+    const size_t N = 20000;                                              // > 2 x 4096: every batch entry shards
+    std::vector<Scalar> a(N), b(N), c(N);
+    for (size_t i = 0; i < N; i++) { a[i] = Scalar(0x9E3779B97F4A7C15ull * (i + 1)); b[i] = Scalar(0xC2B2AE3D27D4EB4Full * (i + 3)); c[i] = Scalar(0x165667B19E3779F9ull * (i + 5)); }
+    for (size_t i = 0; i < N; i++) for (int j = 8; j < 31; j++) c[i].le[j] = (uint8_t)(c[i].le[j - 8] * 31 + j);      // full-width scalars
+    a[17] = Scalar(0);                                                   // a point at infinity inside a shard
+
+    // ---- 1. sharded host entries against the single-device results
+    check(gpbc_set_host_sharding(0));
+    std::vector<G1Affine> P1 = G1ScalarMultiplicationBatch({g1}, a), Pc1 = G1ScalarMultiplicationBatch(P1, c);
+    std::vector<G2Affine> Q1 = G2ScalarMultiplicationBatch({g2}, b), Qc1 = G2ScalarMultiplicationBatch(Q1, c);
+    std::vector<GT> E1 = PairBatch(P1, Q1);
+    check(gpbc_set_host_sharding(1));
+    std::vector<G1Affine> P = G1ScalarMultiplicationBatch({g1}, a), Pc = G1ScalarMultiplicationBatch(P, c);
+    std::vector<G2Affine> Q = G2ScalarMultiplicationBatch({g2}, b), Qc = G2ScalarMultiplicationBatch(Q, c);
+    std::vector<GT> E = PairBatch(P, Q);
+    EXPECT(same(P, P1) && same(Q, Q1) && same(Pc, Pc1) && same(Qc, Qc1) && same(E, E1));
+    EXPECT(P[17].IsInfinity());
+
+    // ragged multi-pairing segments (lengths 0..12) + PairingCheck over the same table
+    std::vector<uint64_t> seg(1, 0);
+    while (seg.back() + 13 <= N) seg.push_back(seg.back() + (seg.size() * 7) % 13);
+    const size_t k = seg.size() - 1, npairs = (size_t)seg.back();
+    std::vector<GT> M(k), M1(k);
+    std::vector<uint8_t> ok(k), ok1(k);
+    check(gpbc_set_host_sharding(0));
+    check(gpbc_multi_pair(P.data(), Q.data(), seg.data(), k, M1.data()));
+    check(gpbc_pairing_check(P.data(), Q.data(), seg.data(), k, ok1.data()));
+    check(gpbc_set_host_sharding(1));
+    check(gpbc_multi_pair(P.data(), Q.data(), seg.data(), k, M.data()));
+    check(gpbc_pairing_check(P.data(), Q.data(), seg.data(), k, ok.data()));
+    EXPECT(same(M, M1) && same(ok, ok1) && npairs > 8192);
+    // fixed-Q: 600 segments x 16 pairs against one list
+    {
+        const size_t m = 16, ks = 600;
+        std::vector<G2Affine> Qm(Q.begin(), Q.begin() + m);
+        std::vector<G1Affine> Pm(P.begin(), P.begin() + m * ks);
+        check(gpbc_set_host_sharding(0));
+        std::vector<GT> F1 = PairFixedQ(Pm, Qm);
+        check(gpbc_set_host_sharding(1));
+        std::vector<GT> F = PairFixedQ(Pm, Qm);
+        EXPECT(same(F, F1));
+    }
+    // GT.Exp / GT.Mul, wire formats
+    {
+        std::vector<GT> X(N), X1(N), Y(N), Y1(N);
+        check(gpbc_set_host_sharding(0));
+        check(gpbc_gt_exp_batch(E.data(), c.data(), N, X1.data()));
+        check(gpbc_gt_mul_batch(E.data(), X1.data(), N, Y1.data()));
+        check(gpbc_set_host_sharding(1));
+        check(gpbc_gt_exp_batch(E.data(), c.data(), N, X.data()));
+        check(gpbc_gt_mul_batch(E.data(), X.data(), N, Y.data()));
+        EXPECT(same(X, X1) && same(Y, Y1));
+        std::vector<uint8_t> w(N * 64), w1(N * 64), okw(N);
+        std::vector<G2Affine> back(N);
+        check(gpbc_g2_marshal_batch(Q.data(), N, 1, w.data()));
+        check(gpbc_set_host_sharding(0));
+        check(gpbc_g2_marshal_batch(Q.data(), N, 1, w1.data()));
+        check(gpbc_set_host_sharding(1));
+        check(gpbc_g2_unmarshal_batch(w.data(), 64, N, back.data(), okw.data()));
+        EXPECT(w == w1 && same(back, Q));
+        for (size_t i = 0; i < N; i++) EXPECT(okw[i] == 1);
+    }
+    // point sums and the aggregate-verify sums: sum_i [c_i] P_i must equal the sum of the products, on any number of devices
+    G1Affine A, A1, As; G2Affine B, B1, Bs;
+    check(gpbc_g1_scalar_mul_sum(P.data(), c.data(), N, &A));
+    check(gpbc_g2_scalar_mul_sum(Q.data(), c.data(), N, &B));
+    check(gpbc_set_host_sharding(0));
+    check(gpbc_g1_scalar_mul_sum(P.data(), c.data(), N, &A1));
+    check(gpbc_g2_scalar_mul_sum(Q.data(), c.data(), N, &B1));
+    check(gpbc_g1_sum(Pc.data(), N, &As));
+    check(gpbc_g2_sum(Qc.data(), N, &Bs));
+    check(gpbc_set_host_sharding(1));
+    EXPECT(A.Equal(A1) && A.Equal(As) && B.Equal(B1) && B.Equal(Bs) && !A.IsInfinity());
+    {   // a sum long enough for gpbc_g1_sum itself to shard (>= 2 x 65536 points): the batch repeated 7 times = 7 x the sum
+        std::vector<G1Affine> rep;
+        for (int r = 0; r < 7; r++) rep.insert(rep.end(), Pc.begin(), Pc.end());
+        G1Affine S7, want7;
+        check(gpbc_g1_sum(rep.data(), rep.size(), &S7));
+        want7.ScalarMultiplication(As, Scalar(7));
+        EXPECT(S7.Equal(want7));
+    }
+    printf("sharded host entries identical to one device: %zu pairings, %zu ragged segments, scalar mults, GT, wire, sums\n", N, k);
+
+    // ---- 2. one host thread per device slot, device-resident buffers, own stream
+    {
+        std::vector<int> bad(nd, 0);
+        std::vector<std::thread> th;
+        for (int d = 0; d < nd; d++)
+            th.emplace_back([&, d]() {
+                auto fail_here = [&](int line) { printf("thread %d failed at line %d: %s\n", d, line, gpbc_last_error()); bad[d] = 1; };
+                if (gpbc_set_device(d) < 0) return fail_here(__LINE__);
+                if (hipSetDevice(gpbc_device_at(d)) != hipSuccess) return fail_here(__LINE__);
+                size_t lo = N * d / nd, hi = N * (d + 1) / nd, m = hi - lo;
+                hipStream_t st;
+                void *dP, *dQ, *dE;
+                if (hipStreamCreate(&st) != hipSuccess) return fail_here(__LINE__);
+                if (hipMalloc(&dP, m * 64) != hipSuccess || hipMalloc(&dQ, m * 128) != hipSuccess || hipMalloc(&dE, m * 384) != hipSuccess) return fail_here(__LINE__);
+                hipMemcpyAsync(dP, &P[lo], m * 64, hipMemcpyHostToDevice, st);
+                hipMemcpyAsync(dQ, &Q[lo], m * 128, hipMemcpyHostToDevice, st);
+                if (gpbc_pair_batch_dev(dP, dQ, m, dE, st) < 0) return fail_here(__LINE__);
+                std::vector<GT> out(m);
+                hipMemcpyAsync(out.data(), dE, m * 384, hipMemcpyDeviceToHost, st);
+                if (hipStreamSynchronize(st) != hipSuccess) return fail_here(__LINE__);
+                if (std::memcmp(out.data(), &E[lo], m * 384) != 0) return fail_here(__LINE__);
+                hipFree(dP); hipFree(dQ); hipFree(dE); hipStreamDestroy(st);
+            });
+        for (auto &t : th) t.join();
+        for (int d = 0; d < nd; d++) EXPECT(bad[d] == 0);
+        printf("one thread per device slot with *_dev entries: OK\n");
+    }
+
+    // ---- 3. RCCL all-gather inside the library (distinct devices only: RCCL refuses a GPU listed twice)
+    if (shared_gpu) Init(std::vector<int>{0});
+    const int nr = NumDevices();
+    if (gpbc_comm_init_all() < 0) { printf("FAIL: gpbc_comm_init_all: %s\n", gpbc_last_error()); return 1; }
+    EXPECT(gpbc_comm_ranks() == nr);
+    {
+        const size_t rows = 1024, bytes = rows * 384;                    // GT rows per rank (BASELINE config 5 shape)
+        std::vector<void *> send(nr), recv(nr);
+        for (int d = 0; d < nr; d++) {
+            HIP_OK(hipSetDevice(gpbc_device_at(d)));
+            HIP_OK(hipMalloc(&send[d], bytes)); HIP_OK(hipMalloc(&recv[d], bytes * nr));
+            HIP_OK(hipMemcpy(send[d], &E[d * rows], bytes, hipMemcpyHostToDevice));
+        }
+        check(gpbc_allgather_all_dev(send.data(), bytes, recv.data(), nullptr));
+        for (int d = 0; d < nr; d++) {
+            std::vector<GT> got(rows * nr);
+            HIP_OK(hipSetDevice(gpbc_device_at(d)));
+            HIP_OK(hipDeviceSynchronize());
+            HIP_OK(hipMemcpy(got.data(), recv[d], bytes * nr, hipMemcpyDeviceToHost));
+            EXPECT(std::memcmp(got.data(), E.data(), bytes * nr) == 0);
+            hipFree(send[d]); hipFree(recv[d]);
+        }
+        // the aggregate-verify sums again, now with the partial sums exchanged by RCCL
+        G1Affine Ar; G2Affine Br;
+        check(gpbc_g1_scalar_mul_sum(P.data(), c.data(), N, &Ar));
+        check(gpbc_g2_scalar_mul_sum(Q.data(), c.data(), N, &Br));
+        EXPECT(Ar.Equal(A) && Br.Equal(B));
+        // _dev form on rank 0's device: with a one-rank communicator the global sum is the local one
+        if (nr == 1) {
+            void *dB, *dS, *dO;
+            HIP_OK(hipMalloc(&dB, N * 64)); HIP_OK(hipMalloc(&dS, N * 32)); HIP_OK(hipMalloc(&dO, 64));
+            HIP_OK(hipMemcpy(dB, P.data(), N * 64, hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(dS, c.data(), N * 32, hipMemcpyHostToDevice));
+            check(gpbc_g1_scalar_mul_sum_dev(dB, dS, N, dO, nullptr));
+            G1Affine Ad;
+            HIP_OK(hipDeviceSynchronize());
+            HIP_OK(hipMemcpy(&Ad, dO, 64, hipMemcpyDeviceToHost));
+            EXPECT(Ad.Equal(A));
+            hipFree(dB); hipFree(dS); hipFree(dO);
+        }
+    }
+    check(gpbc_comm_destroy());
+    EXPECT(gpbc_comm_ranks() == 0);
+    printf("RCCL all-gather over %d rank(s) inside the library: OK\n", nr);
+
+    // BLS aggregate verification (BASELINE config 3) through the boundary: x_i secret keys, pk_i = [x_i]g1, sigma_i = [x_i]H,
+    // check e(sum rho_i pk_i, H) * e(g1, -sum rho_i sigma_i) == 1, then forge one signature.
+    {
+        const size_t n = 10000;
+        G2Affine H; H.ScalarMultiplicationBase(Scalar(0xABCDEF12345ull));
+        std::vector<Scalar> x(a.begin() + 100, a.begin() + 100 + n), rho(c.begin(), c.begin() + n);
+        for (auto &r : rho) for (int j = 16; j < 32; j++) r.le[j] = 0;                 // 128-bit verifier scalars
+        std::vector<G1Affine> pk = G1ScalarMultiplicationBatch({g1}, x);
+        std::vector<G2Affine> sig = G2ScalarMultiplicationBatch({H}, x);
+        G1Affine Ag; G2Affine Bg, nB;
+        check(gpbc_g1_scalar_mul_sum(pk.data(), rho.data(), n, &Ag));
+        check(gpbc_g2_scalar_mul_sum(sig.data(), rho.data(), n, &Bg));
+        nB.Neg(Bg);
+        EXPECT(PairingCheck({Ag, g1}, {H, nB}));
+        sig[n / 2] = sig[n / 2 + 1];
+        check(gpbc_g2_scalar_mul_sum(sig.data(), rho.data(), n, &Bg));
+        nB.Neg(Bg);
+        EXPECT(!PairingCheck({Ag, g1}, {H, nB}));
+        printf("BLS aggregate verify of %zu signatures: accepts, rejects a forged one\n", n);
+    }
+    check(gpbc_shutdown());
+    printf("multi-device OK\n");
+    return 0;
+}

@@ -100,3 +100,36 @@ def test_integration_doc_uses_only_declared_symbols():
     assert not unknown, unknown
     missing = {d for d in declared if d not in doc and not any(d.startswith(u) and u != d for u in used)}
     assert not missing, missing
+
+
+def test_wrapper_rejects_malformed_device_arguments():
+    """The torch (HBM-resident) paths hand raw data_ptr()s to the C ABI, so sizes, dtypes and devices are checked on the host
+    first (a wrong size would be an out-of-bounds device access).  Runs without a GPU: the checks come before any C call."""
+    import torch
+    from gopairingbasedcryptography_amd import bn254
+    z = lambda n: torch.zeros(n, dtype=torch.uint8)
+    P, Q = z(4 * 64), z(4 * 128)
+    bad = [
+        lambda: bn254.pair_batch(P, z(3 * 128)),                              # Q shorter than P
+        lambda: bn254.pair_batch(P, Q, out=z(3 * 384)),                       # caller's out too small
+        lambda: bn254.pair_batch(P, Q.to(torch.int8)),                        # dtype
+        lambda: bn254.pair_batch(P, Q),                                       # right sizes, but host tensors: not CUDA
+        lambda: bn254.miller_loop(P, z(5 * 128)),
+        lambda: bn254.multi_pair(P, Q, [0, 4], out=z(2 * 384)),
+        lambda: bn254.multi_pair(P, Q, torch.tensor([0, 4], dtype=torch.int32)),   # device table read as uint64
+        lambda: bn254.g1_scalar_mul(z(64), z(4 * 32), out=z(3 * 64)),
+        lambda: bn254.g1_scalar_mul(z(2 * 64), z(4 * 32)),                    # 2 bases for 4 scalars
+        lambda: bn254.g2_scalar_mul(np.zeros(128, dtype=np.uint8), z(32)),    # host bases with device scalars
+        lambda: bn254.gt_exp(z(4 * 384), z(3 * 32)),                          # one exponent short
+        lambda: bn254.gt_exp(z(4 * 384), z(4 * 32), out=z(384)),
+        lambda: bn254.gt_mul(z(4 * 384), z(3 * 384)),
+        lambda: bn254.gt_div(z(4 * 384), z(5 * 384)),
+        lambda: bn254.g1_scalar_mul_sum(z(3 * 64), z(4 * 32)),
+        lambda: bn254.multi_pair_fixed_q(z(6 * 64), z(4 * 128)),              # 6 points are not a multiple of the 4-point list
+        lambda: bn254.g1_unmarshal(z(65), elem_bytes=32),
+    ]
+    bn254._slots = bn254._slots or {0: 0}                                     # as after init(0); no device is touched below
+    for i, call in enumerate(bad):
+        with pytest.raises(ValueError):
+            call()
+        assert True, i

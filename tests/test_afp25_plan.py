@@ -34,3 +34,18 @@ def test_batched_decrypt_matches_reference_shape(oracle):
     # an identity outside the batch cannot decrypt (afp25_bibe_test.go:298-370)
     with pytest.raises(ValueError, match="identity not found"):
         afp25.decrypt_batch(eng, inst.g1, inst.tau_powers, inst.D, inst.f, inst.sk, [(12345, inst.items[0][1], inst.items[0][2])])
+
+
+def test_duplicated_identity_is_an_error_as_in_the_reference(oracle):
+    """bibe/afp25_bibe/afp25_bibe.go:371-381 removes every identity equal to id and errors unless exactly one was removed: a
+    batch that lists an identity twice cannot be decrypted for it, although id is still a root of f."""
+    eng = Eng(oracle)
+    inst = Instance(eng, B=6, n_items=2)
+    ids = list(inst.ids)
+    out = afp25.decrypt_batch(eng, inst.g1, inst.tau_powers, inst.D, inst.f, inst.sk, inst.items, identities=ids)
+    assert (out[0] == inst.msgs[0]).all()
+    dup = ids + [inst.items[0][0]]
+    with pytest.raises(ValueError, match="identity not found in identity list"):
+        afp25.decrypt_batch(eng, inst.g1, inst.tau_powers, inst.D, inst.f, inst.sk, inst.items[:1], identities=dup)
+    with pytest.raises(ValueError, match="identity not found in identity list"):
+        afp25.decrypt_batch(eng, inst.g1, inst.tau_powers, inst.D, inst.f, inst.sk, inst.items[:1], identities=[i for i in ids if i != inst.items[0][0]])

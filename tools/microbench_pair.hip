@@ -27,8 +27,13 @@ __global__ void __launch_bounds__(64, 2) bench(const uint8_t *in, uint8_t *out, 
         else if (OP == 5) { h.b0 = f2_sqr(h.b0); h.b1 = f2_sqr(h.b1); h.b2 = f2_sqr(h.b2); }
         else if (OP == 6) { h = f6_reduce(f6_norm(f6_add(h, g))); }
         else if (OP == 7) { h = f6_norm(f6_add(h, x.swap(h))); }
+        // single-lane forms (tower29.cuh): one whole Fp12 value per lane, 64 values per wave-call instead of 32
+        else if (OP == 8) { F12 z = f12_cyclo_sqr(F12{h, g}); h = z.c0; g = z.c1; }
+        else if (OP == 9) { F12 z = f12_mul(F12{h, g}, F12{g, h}); h = z.c0; g = z.c1; }
+        else if (OP == 10) { F12 z = f12_sqr(F12{h, g}); h = f6_reduce(z.c0); g = f6_reduce(z.c1); }
     }
     uint8_t *o = out + 384 * (i & 63);
+    if (OP >= 8) h = f6_norm(f6_add(h, g));
     fe_store(o, fe_reduce(fe_norm(fe_add(fe_add(h.b0.a0, h.b1.a1), fe_add(h.b2.a0, fe_add(h.b0.a1, fe_add(h.b1.a0, h.b2.a1)))))));
 }
 template <int OP> void run(const char *name, const uint8_t *din, uint8_t *dout, int ncu, int waves, int iters, double mads) {
@@ -61,6 +66,9 @@ int main() {
         run<5>("3 x f2_sqr leaf", din, dout, ncu, w, 400, 3 * 324);
         run<6>("f6 add+norm+reduce", din, dout, ncu, w, 2000, 0);
         run<7>("f6 swap+add+norm", din, dout, ncu, w, 2000, 0);
+        run<8>("1-lane f12_cyclo_sqr (9 F2 sqr)", din, dout, ncu, w, 200, 9 * 324);
+        run<9>("1-lane f12_mul (18 F2 mul)", din, dout, ncu, w, 100, 18 * 486);
+        run<10>("1-lane f12_sqr (12 F2 mul)+reduce", din, dout, ncu, w, 100, 12 * 486);
     }
     return 0;
 }

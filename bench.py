@@ -5,22 +5,30 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One step = one pass of the hot path over one batch: B independent bn254.Pair calls (Miller-loop kernel +
+One step = one pass of the hot path over one batch: B independent bn254.Pair calls (Miller-loop kernels +
 final-exponentiation kernel) on synthetic random points P_i=[k("P",i)]g1, Q_i=[k("Q",i)]g2,
 inputs and outputs resident in HBM.  Each rank owns its own batch of B pairs (weak scaling, no data-path
-collective: SURVEY.md §8e); value = pairs all ranks processed / max-over-ranks time.
+collective: SURVEY.md §8e); value = pairs all ranks processed / max-over-ranks time.  Every rank bit-compares a
+sample of its own outputs with the oracle and the run fails if any rank disagrees.
 
 Extra objects on the JSON line:
-  roofline     the dominant stage (the longer of the Miller stage = k_miller_lines + k_miller_accumulate, and the single
-               k_final_exp launch) against the VALU integer-MAC roofline: algorithmic MACs per launch (nominal 7000 / 5000
-               Fp-mul x 136 MAC x B) / mean duration from HIP events on the launch stream; peak = measured
+  roofline     the single kernel with the largest time per step (rocprofv3 agrees: profiles/) against the VALU integer-MAC
+               roofline: algorithmic MACs per launch (nominal Fp-mul x 136 MAC x pairs) / its mean duration
+               from HIP events on the launch stream (gpbc_profile_begin / _end bracket every launch).  peak = measured
                v_mad_u64_u32 issue rate of one MI355X (profiles/r01_microbench_valu.txt).  bound is "valu": this path is
-               carry-chain integer work, neither HBM- nor MFMA-bound.  `stages` gives both fractions, `traffic` the HBM
-               bytes of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json).
-  cpu_baseline the C restatement (oracle/, "port") timed on the host cores, rank 0, N=1 only, bounded sample.
+               carry-chain integer work, neither HBM- nor MFMA-bound.  `kernels` has every kernel of the step (time, launches,
+               fraction), `stages` the Miller stage and the final exponentiation, `traffic` the HBM bytes of ALL kernels of
+               one step from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json) beside the algorithmic bytes.
+  cpu_baseline the C restatement (oracle/, "port") timed on all host cores this process may use, rank 0, N=1 only, bounded
+               sample; cpu_baseline_1core the same on one thread; actual_fp_mul its instrumented Fp-mul counts.
+  value_pcie_inclusive  the host-pointer entry gpbc_pair_batch on the same batch (upload + kernels + download).
+  secondary    G1/G2 scalar-mult rates, wire / hash-to-curve / fixed-base / GT.Exp rates, and `configs`: BASELINE configs
+               2-4 at their stated sizes (aggregate verification of 2^20 signatures, BSW07 decrypt of 2^16 ciphertexts under
+               both 256-attribute policies, AFP25 batch decryption of 2^18 identities), each timed and checked; with N > 1
+               they shard over the ranks and run their all-gather through the library's own RCCL communicator.
 """
 import argparse
-import hashlib
+import ctypes
 import json
 import os
 import sys
@@ -31,30 +39,32 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import bench_workloads as wl                 # noqa: E402  (synthetic inputs of SURVEY.md §8d)
 
-SEED = 0x424E323534
-R_ORDER = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 MAC_PER_FP_MUL = 136                      # 8x32-bit CIOS: 64 product + 64 reduction + 8
 FP_MUL_MILLER, FP_MUL_FINAL_EXP, FP_MUL_G1, FP_MUL_G2 = 7000, 5000, 2500, 7500   # nominal, fixed for grading
+# nominal split of the Miller loop between its two kernels, from SURVEY §8a-1's per-step figures (point doubling + line ~28
+# of ~99 Fp-mul per doubling step): 2000 for the line phase, 5000 for the Fp12 accumulator
+NOMINAL_FP_MUL = {"k_miller_lines": 2000, "k_miller_accumulate": 5000, "k_final_exp": FP_MUL_FINAL_EXP}
 PEAK_TMAC_PER_S = 34.9                    # measured: v_mad_u64_u32, 8 waves/SIMD (profiles/r01_microbench_valu.txt)
 HBM_PEAK_GBS = 8000.0
 
 
-def bench_scalars(tag, start, n):
-    """k(tag,i) = SHA-256("gpbc-bench/v1/" || tag || LE64(seed) || LE64(i)) mod r, as n x 32 LE bytes."""
-    pre = b"gpbc-bench/v1/" + tag.encode() + SEED.to_bytes(8, "little")
-    out = bytearray(32 * n)
-    for j in range(n):
-        k = int.from_bytes(hashlib.sha256(pre + (start + j).to_bytes(8, "little")).digest(), "big") % R_ORDER
-        out[32 * j:32 * j + 32] = k.to_bytes(32, "little")
-    return np.frombuffer(bytes(out), dtype=np.uint8)
+def usable_cpus():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
 
 
-def cpu_baseline(P, Q, gt_gpu, sample, threads):
-    """Time the C restatement on `sample` pairs of the same workload and use it as the checker for them."""
+def cpu_baseline(P, Q, gt_gpu, B):
+    """Time the C restatement on a bounded sample of the same workload (all usable cores, then one), bit-compare the GPU's
+    outputs on the sample, and report the restatement's instrumented Fp-mul counts."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_lib
     oracle_lib.build()
+    threads = usable_cpus()
+    sample = min(B, 8192 * threads)
     Ps, Qs = P[:sample].cpu().numpy(), Q[:sample].cpu().numpy()
     oracle_lib.pair_batch(Ps[:threads], Qs[:threads], threads=threads)      # warm up the thread pool
     t0 = time.perf_counter()
@@ -62,9 +72,21 @@ def cpu_baseline(P, Q, gt_gpu, sample, threads):
     dt = time.perf_counter() - t0
     if not (ref == gt_gpu[:sample].cpu().numpy()).all():
         raise SystemExit("PARITY FAILURE: GPU pairings differ from the oracle on the cpu_baseline sample")
-    return {"value": sample / dt, "unit": "pairings/s", "cores": threads, "kind": "port",
-            "sample": "%d pairs of the same synthetic batch, C restatement oracle/bn254_oracle.c, OpenMP x%d; "
-                      "GPU output bit-compared on the sample" % (sample, threads)}
+    s1 = min(sample, 8192)
+    t0 = time.perf_counter()
+    oracle_lib.pair_batch(Ps[:s1], Qs[:s1], threads=1)
+    dt1 = time.perf_counter() - t0
+    what = "C restatement oracle/bn254_oracle.c (own port, NOT gnark-crypto: no Go toolchain on the box)"
+    base = {"value": sample / dt, "unit": "pairings/s", "cores": threads, "kind": "port",
+            "sample": "%d pairs of the same synthetic batch, %s, OpenMP x%d of %d host CPUs; GPU output bit-compared on the sample"
+                      % (sample, what, threads, os.cpu_count() or 0)}
+    one = {"value": s1 / dt1, "unit": "pairings/s", "cores": 1, "kind": "port", "sample": "%d pairs, one thread" % s1}
+    counts = None
+    try:
+        counts = oracle_lib.fp_mul_counts()
+    except Exception as exc:                                                # noqa: BLE001
+        counts = {"error": repr(exc)}
+    return base, one, counts
 
 
 def main():
@@ -73,8 +95,10 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=1 << 20, help="pairs per GPU per step (metric: 2^20)")
-    ap.add_argument("--cpu-sample", type=int, default=0, help="pairs for the CPU baseline (0 = auto, ~20 s)")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the G1/G2 scalar-mult throughput lines")
+    ap.add_argument("--no-secondary", action="store_true", help="headline line only (scalar-mult rates, extras and config legs skipped)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE config 2-4 legs")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline (profiling runs)")
+    ap.add_argument("--config-scale", type=int, default=1, help="divide the config-leg sizes by this (quick runs; 1 = BASELINE sizes)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -99,60 +123,98 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    from gopairingbasedcryptography_amd import _build, bn254
+    from gopairingbasedcryptography_amd import _build, _lib, afp25, bn254, bsw07, sharding
     if rank == 0:
         _build.build_library()
     if use_dist:
         dist.barrier()
     bn254.init(local_rank)
-
-    B = args.batch
-    # ---- synthetic inputs, generated by the engine's own scalar-mul kernels (timed as the secondary metric)
-    g1, g2 = bn254.generators()
-    g1d, g2d = torch.from_numpy(g1).to(dev), torch.from_numpy(g2).to(dev)
-    kP = torch.from_numpy(bench_scalars("P", rank * B, B).copy()).to(dev)
-    kQ = torch.from_numpy(bench_scalars("Q", rank * B, B).copy()).to(dev)
-    P = bn254.g1_scalar_mul(g1d, kP)
-    Q = bn254.g2_scalar_mul(g2d, kQ)
-    torch.cuda.synchronize()
-    f = torch.empty((B, 384), dtype=torch.uint8, device=dev)
-    gt = torch.empty((B, 384), dtype=torch.uint8, device=dev)
+    lib = _lib.load()
+    comm_error = None
+    if use_dist:
+        # the library's own RCCL communicator over the same ranks (the all-gather of partial sums / GT rows)
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            sharding.init_library_comm(bn254)
+        except Exception as exc:                                            # noqa: BLE001
+            comm_error = repr(exc)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    import ctypes
-    from gopairingbasedcryptography_amd import _lib
-    lib = _lib.load()
+    def max_over_ranks(d):
+        if use_dist:
+            tm = torch.tensor([d], dtype=torch.float64, device=dev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            d = float(tm.item())
+        return d
+
+    def all_ranks_true(flag):
+        if use_dist:
+            t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            flag = bool(t.item())
+        return bool(flag)
+
+    B = args.batch
+    # ---- synthetic inputs, generated by the engine's own scalar-mul kernels (timed as the secondary metric)
+    g1, g2 = bn254.generators()
+    g1d, g2d = torch.from_numpy(g1).to(dev), torch.from_numpy(g2).to(dev)
+    kP = torch.from_numpy(wl.bench_scalars("P", rank * B, B).copy()).to(dev)
+    kQ = torch.from_numpy(wl.bench_scalars("Q", rank * B, B).copy()).to(dev)
+    P = bn254.g1_scalar_mul(g1d, kP)
+    Q = bn254.g2_scalar_mul(g2d, kQ)
+    torch.cuda.synchronize()
+    f = torch.empty((B, 384), dtype=torch.uint8, device=dev)
+    gt = torch.empty((B, 384), dtype=torch.uint8, device=dev)
+
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     pP, pQ, pf, pgt = (ctypes.c_void_p(t.data_ptr()) for t in (P, Q, f, gt))
     nB = ctypes.c_size_t(B)
 
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
-
-    def step(e=None):
-        if e: e[0].record()
+    def step():
         _lib.check(lib.gpbc_miller_loop_dev(pP, pQ, nB, pf, stream))
-        if e: e[1].record()
         _lib.check(lib.gpbc_final_exp_dev(pf, nB, pgt, stream))
-        if e: e[2].record()
 
     for _ in range(args.warmup):
         step()
     barrier()
+    _lib.check(lib.gpbc_profile_begin(stream))           # HIP events around every kernel of the timed steps, on their stream
     t0 = time.perf_counter()
     for s in range(args.steps):
-        step(ev[s])
+        step()
     barrier()
     dt = time.perf_counter() - t0
-    if use_dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    miller_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
-    fexp_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+    names = ctypes.create_string_buffer(32 * 16)
+    ms = (ctypes.c_double * 16)()
+    cnt = (ctypes.c_int * 16)()
+    nk = ctypes.c_int(0)
+    _lib.check(lib.gpbc_profile_end(names, ms, cnt, 16, ctypes.byref(nk)))
+    kern = {}
+    for i in range(nk.value):
+        nm = names.raw[32 * i:32 * i + 32].split(b"\0")[0].decode()
+        kern[nm] = {"ms_per_step": ms[i] / args.steps, "launches_per_step": cnt[i] / args.steps, "ms_per_launch": ms[i] / cnt[i]}
+    dt = max_over_ranks(dt)
+    miller_ms = sum(kern[k]["ms_per_step"] for k in ("k_miller_lines", "k_miller_accumulate") if k in kern)
+    fexp_ms = kern.get("k_final_exp", {}).get("ms_per_step", float("nan"))
+
+    # ---- every rank checks a sample of its own outputs against the oracle (the parity claim of the workload string)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_lib
+    oracle_lib.build()
+    si = np.r_[0:48, B // 2:B // 2 + 8, B - 8:B] if B >= 128 else np.arange(B)
+    sample_ok = bool((oracle_lib.pair_batch(P[si].cpu().numpy(), Q[si].cpu().numpy(), threads=min(16, usable_cpus())) == gt[si].cpu().numpy()).all())
+    if not all_ranks_true(sample_ok):
+        raise SystemExit("PARITY FAILURE: rank %d: GPU pairings differ from the oracle on its sample" % rank if not sample_ok
+                         else "PARITY FAILURE on another rank")
 
     value = world * B * args.steps / dt
     result = {
@@ -160,42 +222,53 @@ def main():
         "value": value, "unit": "pairings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "int64", "data": "synthetic",
-        "config": {"workload": "configs[1]: batch of %d independent bn254.Pair on random (G1,G2) points per GPU, "
-                               "bit-exact vs oracle" % B,
+        "config": {"workload": "configs[1]: batch of %d independent bn254.Pair on random (G1,G2) points per GPU; every rank "
+                               "bit-compares %d of its outputs with the oracle (in-repo restatement: parity with gnark-crypto "
+                               "itself is unpinned, tests/test_gnark_vectors.py)" % (B, len(si)),
                    "batch_per_gpu": B, "sharding": "independent index ranges per rank, no data-path collective",
                    "arithmetic": "254-bit Montgomery integers as 9 signed 29-bit limbs (int32), 32x32+64-bit MACs into int64 columns"},
     }
-    # ---- roofline, VALU integer-MAC bound.  One step launches the Miller stage (k_miller_lines + k_miller_accumulate per
-    # 262144-pair chunk) and ONE k_final_exp over the whole batch; the dominant kernel is whichever stage took longer.
-    stages = {
-        "miller_loop (k_miller_lines + k_miller_accumulate)": (miller_ms, FP_MUL_MILLER),
-        "k_final_exp": (fexp_ms, FP_MUL_FINAL_EXP),
-    }
-    dom = max(stages, key=lambda k: stages[k][0])
-    dom_ms, dom_fpmul = stages[dom]
-    achieved = dom_fpmul * MAC_PER_FP_MUL * B / (dom_ms * 1e-3) / 1e12
+    # ---- roofline, VALU integer-MAC bound: the single kernel with the largest time per step
+    frac = lambda fpmul, t_ms: fpmul * MAC_PER_FP_MUL * B / (t_ms * 1e-3) / 1e12 / PEAK_TMAC_PER_S
+    for k, v in kern.items():
+        if k in NOMINAL_FP_MUL:
+            v["nominal_fp_mul"] = NOMINAL_FP_MUL[k]
+            v["frac"] = frac(NOMINAL_FP_MUL[k], v["ms_per_step"])
+    dom = max((k for k in kern if k in NOMINAL_FP_MUL), key=lambda k: kern[k]["ms_per_step"])
+    launches = kern[dom]["launches_per_step"]
+    achieved = NOMINAL_FP_MUL[dom] * MAC_PER_FP_MUL * (B / launches) / (kern[dom]["ms_per_launch"] * 1e-3) / 1e12
     algo_bytes = B * (64 + 128 + 384)
-    traffic = None
+    traffic, per_kernel_traffic = None, {}
     tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")          # written by tools/pmc_run.sh (separate --pmc passes)
     if os.path.exists(tp):
-        t = json.load(open(tp)).get("k_final_exp" if dom == "k_final_exp" else "k_miller_accumulate")
-        if t:   # FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B); KB -> bytes; scaled to this launch
-            traffic = (2 * t["fetch_kb"] + t["write_kb"]) * 1024.0 * (B / t["batch"]) / t.get("launches_per_batch", 1)
+        tj = json.load(open(tp))
+        for k in NOMINAL_FP_MUL:
+            t = tj.get(k)
+            if t:   # FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B); KB -> bytes; per launch, times launches per step
+                per_launch = (2 * t["fetch_kb"] + t["write_kb"]) * 1024.0
+                per_kernel_traffic[k] = per_launch * (B / t["batch"])
+        if len(per_kernel_traffic) == len(NOMINAL_FP_MUL):
+            traffic = sum(per_kernel_traffic.values())
     result["roofline"] = {
         "bound": "valu", "kernel": dom, "achieved": achieved, "peak": PEAK_TMAC_PER_S, "unit": "TMAC/s",
-        "frac": achieved / PEAK_TMAC_PER_S, "traffic": traffic,
-        "kernel_ms": dom_ms,
-        "stages": {k: {"ms": v[0], "nominal_fp_mul": v[1],
-                       "frac": v[1] * MAC_PER_FP_MUL * B / (v[0] * 1e-3) / 1e12 / PEAK_TMAC_PER_S} for k, v in stages.items()},
-        "whole_pairing_frac": (FP_MUL_MILLER + FP_MUL_FINAL_EXP) * MAC_PER_FP_MUL * B / ((miller_ms + fexp_ms) * 1e-3) / 1e12 / PEAK_TMAC_PER_S,
+        "frac": achieved / PEAK_TMAC_PER_S,
+        "kernel_ms_per_launch": kern[dom]["ms_per_launch"], "kernel_launches_per_step": launches, "pairs_per_launch": B / launches,
+        "traffic": traffic, "traffic_unit": "HBM bytes per step, all kernels (PMC FETCH_SIZE x2 + WRITE_SIZE)",
+        "traffic_per_kernel": per_kernel_traffic or None, "algorithmic_bytes": algo_bytes,
+        "traffic_over_algorithmic": (traffic / algo_bytes) if traffic else None,
+        "kernels": kern,
+        "stages": {"miller_loop (k_miller_lines + k_miller_accumulate)": {"ms": miller_ms, "nominal_fp_mul": FP_MUL_MILLER, "frac": frac(FP_MUL_MILLER, miller_ms)},
+                   "k_final_exp": {"ms": fexp_ms, "nominal_fp_mul": FP_MUL_FINAL_EXP, "frac": frac(FP_MUL_FINAL_EXP, fexp_ms)}},
+        "whole_pairing_frac": frac(FP_MUL_MILLER + FP_MUL_FINAL_EXP, miller_ms + fexp_ms),
         "hbm_GBs_algorithmic": algo_bytes / ((miller_ms + fexp_ms) * 1e-3) / 1e9, "hbm_peak_GBs": HBM_PEAK_GBS,
-        "note": "integer carry-chain work: bound is VALU v_mad_i64_i32 issue, not HBM/MFMA (SURVEY.md \u00a78d); peak = measured "
-                "dependency-free v_mad_u64_u32 rate (profiles/r01_microbench_valu.txt); algorithmic MACs = nominal Fp-mul x 136",
+        "note": "integer carry-chain work: bound is VALU v_mad_i64_i32 issue, not HBM/MFMA (SURVEY.md §8d); peak = measured "
+                "dependency-free v_mad_u64_u32 rate (profiles/r01_microbench_valu.txt); algorithmic MACs = nominal Fp-mul x 136; "
+                "kernel times from HIP events on the launch stream around every launch of the timed steps",
     }
+    sec = {}
     # ---- secondary metric: scalar multiplications at the same batch
     if not args.no_secondary:
-        ks = torch.from_numpy(bench_scalars("s", rank * B, B).copy()).to(dev)
-        sec = {}
+        ks = torch.from_numpy(wl.bench_scalars("s", rank * B, B).copy()).to(dev)
         for name, fn, base, nominal in (("g1", bn254.g1_scalar_mul, P, FP_MUL_G1), ("g2", bn254.g2_scalar_mul, Q, FP_MUL_G2)):
             out = torch.empty_like(base)
             fn(base, ks, out=out)                       # untimed warm-up pass
@@ -204,29 +277,20 @@ def main():
             for _ in range(2):
                 fn(base, ks, out=out)
             barrier()
-            d = (time.perf_counter() - t1) / 2
-            if use_dist:
-                tm = torch.tensor([d], dtype=torch.float64, device=dev)
-                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-                d = float(tm.item())
+            d = max_over_ranks((time.perf_counter() - t1) / 2)
             sec[name + "_scalar_mults_per_s"] = world * B / d
             sec[name + "_frac_of_valu_peak"] = nominal * MAC_PER_FP_MUL * B / d / 1e12 / PEAK_TMAC_PER_S
+
         # The remaining lines (wire formats, hash to curve, fixed-base tables, GT.Exp) are per-GPU rates of independent
         # kernels: measured on the single-GPU run only, and never allowed to take the headline JSON line down with them.
         def extras():
-            # wire formats: encode / decode rates of the same batch, HBM-resident
             def rate(fn, *a, **kw):
                 fn(*a, **kw)
                 barrier()
                 t1 = time.perf_counter()
                 fn(*a, **kw)
                 barrier()
-                d = time.perf_counter() - t1
-                if use_dist:
-                    tm = torch.tensor([d], dtype=torch.float64, device=dev)
-                    dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-                    d = float(tm.item())
-                return world * B / d
+                return world * B / max_over_ranks(time.perf_counter() - t1)
             nw = min(B, 1 << 18)                              # the G2 subgroup check makes G2 decoding the slow one
             Pw, Qw, gw = P[:nw].contiguous(), Q[:nw].contiguous(), gt[:nw].contiguous()
             wire = {"batch": nw}
@@ -239,11 +303,9 @@ def main():
             wire["gt_marshal_per_s"] = rate(bn254.gt_marshal, gw) * nw / B
             wire["gt_unmarshal_per_s"] = rate(bn254.gt_unmarshal, bn254.gt_marshal(gw)) * nw / B
             sec["wire"] = wire
-            # hash to curve, group part (§8 f-1): two field elements per point, taken from the scalar stream
-            uf = torch.from_numpy(bench_scalars("h2c", rank * nw * 4, nw * 4).copy()).to(dev).reshape(-1, 32)   # values < r < p: valid fp.Elements
+            uf = torch.from_numpy(wl.bench_scalars("h2c", rank * nw * 4, nw * 4).copy()).to(dev).reshape(-1, 32)   # values < r < p: valid fp.Elements
             sec["g1_map_to_curve_per_s"] = rate(bn254.map_to_g1, uf[:2 * nw].reshape(nw, 64).contiguous()) * nw / B
             sec["g2_map_to_curve_per_s"] = rate(bn254.map_to_g2, uf.reshape(nw, 128).contiguous()) * nw / B
-            # fixed-base window tables: generator multiplications (ScalarMultiplicationBase) and 256-term commitments (AFP25 shape)
             fb = bn254.FixedBase(g1d)
             sec["g1_fixed_base_mults_per_s"] = rate(fb.mul, ks)
             fb.close()
@@ -251,23 +313,6 @@ def main():
             fbs = bn254.FixedBase(P[:nsrs].contiguous())
             sec["g1_msm256_terms_per_s"] = rate(fbs.msm, ks[:nsrs * nmsm].contiguous()) * (nsrs * nmsm) / B
             fbs.close()
-            # multi-pairing shapes of BASELINE configs 4 and 5 (pairs/s, one final exponentiation per segment)
-            def pairs_rate(fn, n_pairs, *a):
-                fn(*a)
-                barrier()
-                t1 = time.perf_counter()
-                fn(*a)
-                barrier()
-                return n_pairs / (time.perf_counter() - t1)
-            kseg, mseg = 1024, 513                            # a 256-attribute BSW07 decrypt: 513 pairs per ciphertext
-            if B >= kseg * mseg:
-                off = np.arange(0, kseg * mseg + 1, mseg).astype(np.uint64)
-                Pm, Qm = P[:kseg * mseg].contiguous(), Q[:mseg].contiguous()
-                sec["multi_pair_513_fixed_q_pairs_per_s"] = pairs_rate(bn254.multi_pair_fixed_q, kseg * mseg, Pm, Qm)
-                sec["multi_pair_513_pairs_per_s"] = pairs_rate(bn254.multi_pair, kseg * mseg, Pm, Q[:kseg * mseg].contiguous(), off)
-            k3 = min(B // 3, 1 << 17)                         # AFP25 batch decryption: 3 pairs per item
-            off3 = np.arange(0, 3 * k3 + 1, 3).astype(np.uint64)      # table on the host: whole-segment shared squarings
-            sec["multi_pair_3_pairs_per_s"] = pairs_rate(bn254.multi_pair, 3 * k3, P[:3 * k3].contiguous(), Q[:3 * k3].contiguous(), off3)
             ne = min(B, 1 << 16)                              # GT.Exp by full-size exponents
             sec["gt_exp_per_s"] = rate(bn254.gt_exp, gt[:ne].contiguous(), ks[:ne].contiguous()) * ne / B
         if world == 1:
@@ -275,16 +320,119 @@ def main():
                 extras()
             except Exception as exc:                      # noqa: BLE001
                 sec["extras_error"] = repr(exc)
+
+        # ---- BASELINE configs 2-4 at their stated sizes: totals are fixed (strong scaling over the ranks), every leg is checked
+        def timed(fn):
+            barrier()
+            t1 = time.perf_counter()
+            out = fn()
+            barrier()
+            return out, max_over_ranks(time.perf_counter() - t1)
+
+        def leg_aggregate():
+            n_total = (1 << 20) // args.config_scale
+            lo, hi = sharding.shard_range(n_total, rank, world)
+            inst = wl.aggregate(bn254, hi - lo, dev, start=lo)
+            # B = sum rho_i sigma_i over ALL ranks (untimed here; timed in the second figure)
+            Bsum = bn254.g2_scalar_mul_sum(inst["sigma"], inst["rho"])
+            def literal():                                    # "2^20 G1 scalar-mults + 2 pairings" (BASELINE configs[2])
+                A = bn254.g1_scalar_mul_sum(inst["pk"], inst["rho"])          # + the 64 B-per-rank all-gather inside the library
+                return wl.aggregate_check(bn254, A.cpu().numpy(), Bsum.cpu().numpy(), inst["H"], inst["g1"])
+            literal()
+            ok, t_lit = timed(literal)
+            def full():
+                A = bn254.g1_scalar_mul_sum(inst["pk"], inst["rho"])
+                Bs = bn254.g2_scalar_mul_sum(inst["sigma"], inst["rho"])
+                return wl.aggregate_check(bn254, A.cpu().numpy(), Bs.cpu().numpy(), inst["H"], inst["g1"])
+            ok2, t_full = timed(full)
+            forged = inst["sigma"].clone()
+            if rank == 0:
+                forged[1] = forged[0]
+            Bf = bn254.g2_scalar_mul_sum(forged, inst["rho"])
+            A = bn254.g1_scalar_mul_sum(inst["pk"], inst["rho"])
+            rejected = not wl.aggregate_check(bn254, A.cpu().numpy(), Bf.cpu().numpy(), inst["H"], inst["g1"])
+            return {"workload": "configs[2]: BLS aggregate verification of %d signatures on one message point, random linear "
+                                "combination with 128-bit scalars" % n_total, "signatures": n_total, "scaling": "strong",
+                    "signatures_per_s": n_total / t_lit, "ms": 1e3 * t_lit,
+                    "timed": "sum rho_i pk_i (2^20 G1 scalar-mults + point-sum tree%s) + the 2-pairing check"
+                             % (" + RCCL all-gather of the partial sums inside the library" if world > 1 else ""),
+                    "with_g2_sums_signatures_per_s": n_total / t_full, "with_g2_sums_ms": 1e3 * t_full,
+                    "accepts": all_ranks_true(ok and ok2), "rejects_forged": all_ranks_true(rejected),
+                    "collective": ("library RCCL all-gather, %d ranks" % bn254.comm_ranks()) if world > 1 else None}
+
+        def leg_bsw07(kind):
+            n_total = (1 << 16) // args.config_scale
+            lo, hi = sharding.shard_range(n_total, rank, world)
+            inst = wl.bsw07_instance(bn254, kind, hi - lo, dev, start=lo)
+            plan = bsw07.decrypt_plan(inst["tree"], inst["attrs"])
+            folded = bsw07.fold_key(bn254, plan, inst["dj"], inst["dj_prime"])      # once per (key, policy), untimed
+            run = lambda: bsw07.decrypt_batch_arrays(bn254, folded, inst["D"], inst["c_tilde"], inst["c"], inst["cy"], inst["cy_prime"])
+            run()
+            out, t = timed(run)
+            pairs = n_total * inst["pairs_per_ct"]
+            return {"workload": "configs[3]: cpabe/bsw07 Decrypt, %s policy over 256 attributes, %d ciphertexts x %d pairs "
+                                "(fixed-Q multi-pairing, Lagrange coefficients folded into the key)" % (kind, n_total, inst["pairs_per_ct"]),
+                    "ciphertexts": n_total, "scaling": "strong", "ciphertexts_per_s": n_total / t, "pairs_per_s": pairs / t, "ms": 1e3 * t,
+                    "all_messages_recovered": all_ranks_true(bool((out == inst["msgs"]).all()))}
+
+        def leg_afp25():
+            n_total, Bsz = (1 << 18) // args.config_scale, 256
+            per = (n_total // Bsz // world) * Bsz                                   # whole batches per rank
+            n_total = per * world
+            inst = wl.afp25_instance(bn254, Bsz, per, dev, start=rank * per)
+            gathered = [None]
+            def run():
+                out = afp25.decrypt_batch_arrays(bn254, inst["D"], inst["pi"], inst["sk"], inst["C1"], inst["C2"])
+                if world > 1:                                                      # all-gather of the GT masks (BASELINE configs[4])
+                    gathered[0] = bn254.allgather(out.reshape(-1))
+                return out
+            run()
+            out, t = timed(run)
+            ok = bool((out == inst["msgs"]).all())
+            if world > 1:
+                ok = ok and bool((gathered[0][rank].reshape(per, 384) == out).all())
+            return {"workload": "configs[4]: bibe/afp25_bibe batch decryption of %d identities in batches of %d "
+                                "(3-pair multi-pairing + GT.Div per item%s)" % (n_total, Bsz, ", RCCL all-gather of the GT masks inside the library" if world > 1 else ""),
+                    "items": n_total, "scaling": "strong", "items_per_s": n_total / t, "pairs_per_s": 3 * n_total / t, "ms": 1e3 * t,
+                    "all_messages_recovered": all_ranks_true(ok),
+                    "collective": ("library RCCL all-gather of %d x 384 B per rank, %d ranks" % (per, bn254.comm_ranks())) if world > 1 else None}
+
+        if not args.no_configs:
+            cfg = {}
+            if world > 1 and comm_error:
+                cfg["comm_error"] = comm_error
+            for key, fn in (("aggregate_verify_2^20", leg_aggregate), ("bsw07_256of256_2^16", lambda: leg_bsw07("256of256")),
+                            ("bsw07_16x16_2^16", lambda: leg_bsw07("16x16")), ("afp25_2^18", leg_afp25)):
+                try:
+                    cfg[key] = fn()
+                except Exception as exc:                  # noqa: BLE001
+                    cfg[key] = {"error": repr(exc)}
+                torch.cuda.empty_cache()
+            sec["configs"] = cfg
         result["secondary"] = sec
-    # ---- CPU baseline (rank 0, single-GPU run only)
-    if rank == 0 and world == 1:
-        threads = min(os.cpu_count() or 1, 16)
-        sample = args.cpu_sample or min(B, 640 * threads)
-        result["cpu_baseline"] = cpu_baseline(P, Q, gt, sample, threads)
+    # ---- PCIe-inclusive rate and CPU baseline (rank 0, single-GPU run only)
+    if rank == 0 and world == 1 and not args.no_cpu:
+        try:
+            Ph, Qh = P.cpu().numpy(), Q.cpu().numpy()
+            bn254.pair_batch(Ph[:4096], Qh[:4096])
+            t1 = time.perf_counter()
+            gh = bn254.pair_batch(Ph, Qh)
+            d = time.perf_counter() - t1
+            result["value_pcie_inclusive"] = {"value": B / d, "unit": "pairings/s", "identical_to_hbm_resident_run": bool((gh == gt.cpu().numpy()).all()),
+                                              "what": "gpbc_pair_batch on pageable host buffers: hipMalloc + 192 B/pair up + kernels + 384 B/pair down"}
+            del Ph, Qh, gh
+        except Exception as exc:                          # noqa: BLE001
+            result["value_pcie_inclusive"] = {"error": repr(exc)}
+        base, one, counts = cpu_baseline(P, Q, gt, B)
+        result["cpu_baseline"], result["cpu_baseline_1core"], result["actual_fp_mul"] = base, one, counts
     if rank == 0:
         print(json.dumps(result))
     if use_dist:
         dist.barrier()
+        try:
+            bn254.comm_destroy()
+        except Exception:                                 # noqa: BLE001
+            pass
         dist.destroy_process_group()
 
 

@@ -21,7 +21,7 @@ EXPORTS = [
     "gpbc_g1_sum_dev", "gpbc_g2_sum_dev",
     "gpbc_gt_exp_batch", "gpbc_gt_exp_batch_dev", "gpbc_gt_mul_batch", "gpbc_gt_div_batch",
     "gpbc_gt_inverse_batch", "gpbc_gt_mul_batch_dev", "gpbc_gt_div_batch_dev", "gpbc_gt_inverse_batch_dev",
-    "gpbc_fp_mul_batch",
+    "gpbc_fp_mul_batch", "gpbc_profile_begin", "gpbc_profile_end",
     "gpbc_g1_marshal_batch", "gpbc_g2_marshal_batch", "gpbc_gt_marshal_batch",
     "gpbc_g1_marshal_batch_dev", "gpbc_g2_marshal_batch_dev", "gpbc_gt_marshal_batch_dev",
     "gpbc_g1_unmarshal_batch", "gpbc_g2_unmarshal_batch", "gpbc_gt_unmarshal_batch",

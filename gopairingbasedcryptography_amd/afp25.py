@@ -95,3 +95,21 @@ def decrypt_batch(engine, g1, tau_powers, D, f_coeffs, sk, items, table=None, id
     off = np.arange(0, 3 * len(items) + 1, 3)
     X = engine.multi_pair(np.concatenate(P_rows), np.concatenate(Q_rows), off)
     return engine.gt_div(np.stack(c2), X)
+
+
+def decrypt_batch_arrays(engine, D, pi, sk, C1, C2):
+    """The pairing part of the batch decryption on arrays (numpy, or CUDA tensors): item i is decrypted with its batch's
+    digest D[i], its opening proof pi[i] and key sk[i] — m_i = C2_i / (e(D_i, C1_i[0]) e(pi_i, C1_i[1]) e(sk_i, C1_i[2]))
+    (bibe/afp25_bibe/afp25_bibe.go:395-413): ONE multi-pairing of 3-pair segments and one gt_div, BASELINE config 5 at its
+    stated size.  D, pi, sk: [n,64]; C1: [n,3,128]; C2: [n,384]."""
+    if type(D).__module__.startswith("torch"):
+        import torch
+        n = D.numel() // 64
+        P = torch.stack([D.reshape(n, 64), pi.reshape(n, 64), sk.reshape(n, 64)], dim=1).contiguous()
+        X = engine.multi_pair(P.reshape(-1), C1.reshape(-1).contiguous(), np.arange(0, 3 * n + 1, 3, dtype=np.uint64))
+        return engine.gt_div(C2.reshape(n, 384).contiguous(), X)
+    n = np.asarray(D).size // 64
+    P = np.stack([np.asarray(D, dtype=np.uint8).reshape(n, 64), np.asarray(pi, dtype=np.uint8).reshape(n, 64),
+                  np.asarray(sk, dtype=np.uint8).reshape(n, 64)], axis=1)
+    X = engine.multi_pair(P, np.asarray(C1, dtype=np.uint8).reshape(3 * n, 128), np.arange(0, 3 * n + 1, 3))
+    return engine.gt_div(np.asarray(C2, dtype=np.uint8).reshape(n, 384), X)

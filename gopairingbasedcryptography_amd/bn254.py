@@ -108,6 +108,27 @@ def generators():
             np.frombuffer(bytes.fromhex(_G2_GEN_HEX), dtype=np.uint8).copy())
 
 
+P_MODULUS = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+
+
+def _fp_neg_bytes(b):
+    """p - y on one 32-byte little-endian Montgomery value (the negation of yR mod p is (p - y)R mod p); 0 stays 0."""
+    v = int.from_bytes(bytes(b), "little")
+    return ((P_MODULUS - v) % P_MODULUS).to_bytes(32, "little")
+
+
+def g1_neg(pt):
+    """G1Affine.Neg on one 64-byte point (host side, like the field negation of include/gpbc_bn254.hpp): (x, -y)."""
+    b = np.asarray(pt, dtype=np.uint8).reshape(G1_BYTES).tobytes()
+    return np.frombuffer(b[:32] + _fp_neg_bytes(b[32:]), dtype=np.uint8).copy()
+
+
+def g2_neg(pt):
+    """G2Affine.Neg on one 128-byte point: (x, -y) with y in Fp2."""
+    b = np.asarray(pt, dtype=np.uint8).reshape(G2_BYTES).tobytes()
+    return np.frombuffer(b[:64] + _fp_neg_bytes(b[64:96]) + _fp_neg_bytes(b[96:]), dtype=np.uint8).copy()
+
+
 # --------------------------------------------------------------------------------------- torch (HBM-resident) path
 def _torch_stream():
     import torch

@@ -118,3 +118,26 @@ def decrypt_batch(engine, folded, d_key, cts, neg_g1):
         off = np.arange(0, len(cts) * m + 1, m)
         X = engine.multi_pair(np.concatenate(P_rows), np.concatenate([Q_seg] * len(cts)), off)
     return engine.gt_mul(np.stack(ctil), X)                                          # C~ * A / e(C, D) per ciphertext
+
+
+def decrypt_batch_arrays(engine, folded, d_key, c_tilde, c, cy, cy_prime):
+    """The same decryption on arrays (numpy, or CUDA tensors for HBM-resident ciphertexts): n ciphertexts under one
+    (key, policy) plan, BASELINE config 4 at its stated size (2^16 ciphertexts x (2 x 256 + 1) pairs).
+
+    c_tilde [n,384], c [n,64]; cy, cy_prime [n,l,64] with the l columns in the order of folded's leaf ids.  The factor
+    1 / e(C, D) enters as e(C, -D) — one host-side negation of the key's D instead of n negations of C (both equal
+    e(C, D)^-1 exactly) — so the G2 list [Dj^..., Dj'^..., -D] is the same for every ciphertext: one fixed-Q multi-pairing
+    (2l+1 line evaluations and one final exponentiation per ciphertext) and one gt_mul."""
+    leaf_ids, dj_hat, djp_hat = folded
+    l = len(leaf_ids)
+    q_list = np.concatenate([np.asarray(dj_hat).reshape(l, 128), np.asarray(djp_hat).reshape(l, 128), engine.g2_neg(d_key).reshape(1, 128)])
+    if type(c).__module__.startswith("torch"):
+        import torch
+        n = c.numel() // 64
+        P = torch.cat([cy.reshape(n, l, 64), cy_prime.reshape(n, l, 64), c.reshape(n, 1, 64)], dim=1).contiguous()
+        Q = torch.from_numpy(np.ascontiguousarray(q_list)).to(c.device)
+        return engine.gt_mul(c_tilde.reshape(n, 384).contiguous(), engine.multi_pair_fixed_q(P.reshape(-1), Q.reshape(-1)))
+    n = np.asarray(c).size // 64
+    P = np.concatenate([np.asarray(cy, dtype=np.uint8).reshape(n, l, 64), np.asarray(cy_prime, dtype=np.uint8).reshape(n, l, 64),
+                        np.asarray(c, dtype=np.uint8).reshape(n, 1, 64)], axis=1)
+    return engine.gt_mul(np.asarray(c_tilde, dtype=np.uint8).reshape(n, 384), engine.multi_pair_fixed_q(P, q_list))

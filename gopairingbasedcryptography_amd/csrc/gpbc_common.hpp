@@ -68,6 +68,7 @@ int comm_rank();
 int comm_allgather(const void *d_send, size_t bytes, void *d_recv, hipStream_t st);
 static inline unsigned grid_for(size_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
 int check_launch(const char *what);
+void profile_mark(const char *kernel_name, hipStream_t st);   // bench.py's per-kernel timing (gpbc_profile_begin / _end); a no-op otherwise
 int sync_default();
 
 // RAII device buffer for the host-pointer entry points

@@ -181,6 +181,23 @@ int comm_allgather(const void *d_send, size_t bytes, void *d_recv, hipStream_t s
     return GPBC_OK;
 }
 
+// ---- per-kernel timing for bench.py (HIP events on the launch stream).  Entries call profile_mark(name, stream) right
+// after a launch; with profiling on, that records an event, and the time between consecutive marks of a stream is the
+// duration of the kernel that ended at the later one (the stream is kept busy, so there are no gaps to speak of).
+struct ProfMark { char name[32]; hipEvent_t ev; };
+static std::mutex g_prof_mu;
+static std::vector<ProfMark> g_prof;
+static std::atomic<int> g_prof_on{0};
+void profile_mark(const char *name, hipStream_t st) {
+    if (!g_prof_on.load()) return;
+    ProfMark m;
+    snprintf(m.name, sizeof m.name, "%s", name);
+    if (hipEventCreate(&m.ev) != hipSuccess) return;
+    if (hipEventRecord(m.ev, st) != hipSuccess) { (void)hipEventDestroy(m.ev); return; }
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.push_back(m);
+}
+
 __global__ void __launch_bounds__(BLOCK) k_fp_mul(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, uint8_t *__restrict__ out, size_t n) {
     size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -318,6 +335,44 @@ int gpbc_allgather_all_dev(const void *const *d_send, size_t bytes_per_rank, voi
     }
     NCCL_TRY(g_rccl.GroupEnd());
     return GPBC_OK;
+}
+
+int gpbc_profile_begin(void *stream) {
+    TRY(bind_device());
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        for (auto &m : g_prof) (void)hipEventDestroy(m.ev);
+        g_prof.clear();
+    }
+    g_prof_on.store(1);
+    profile_mark("(begin)", (hipStream_t)stream);
+    return GPBC_OK;
+}
+int gpbc_profile_end(char *names_out, double *total_ms_out, int *launches_out, int max_kernels, int *n_kernels_out) {
+    if (!names_out || !total_ms_out || !launches_out || !n_kernels_out || max_kernels < 1) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    g_prof_on.store(0);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    int n = 0;
+    int rc = GPBC_OK;
+    if (!g_prof.empty() && hipEventSynchronize(g_prof.back().ev) != hipSuccess) rc = fail(GPBC_ERR_HIP, "hipEventSynchronize failed");
+    for (size_t i = 1; rc == GPBC_OK && i < g_prof.size(); i++) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, g_prof[i - 1].ev, g_prof[i].ev) != hipSuccess) { rc = fail(GPBC_ERR_HIP, "hipEventElapsedTime failed"); break; }
+        int k = 0;
+        while (k < n && strncmp(names_out + 32 * k, g_prof[i].name, 32) != 0) k++;
+        if (k == n) {
+            if (n == max_kernels) continue;
+            memset(names_out + 32 * k, 0, 32);
+            snprintf(names_out + 32 * k, 32, "%s", g_prof[i].name);
+            total_ms_out[k] = 0; launches_out[k] = 0;
+            n++;
+        }
+        total_ms_out[k] += ms; launches_out[k]++;
+    }
+    for (auto &m : g_prof) (void)hipEventDestroy(m.ev);
+    g_prof.clear();
+    *n_kernels_out = n;
+    return rc;
 }
 
 int gpbc_fp_mul_batch(const void *a, const void *b, size_t n, void *out) {

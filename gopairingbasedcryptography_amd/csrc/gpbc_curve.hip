@@ -157,12 +157,14 @@ static int shared_base_mul_dev(bool g2, const void *d_base, const void *d_scalar
             if (g2) k_g2_fb_build<<<grid_for(FB_ENTRIES), BLOCK, 0, st>>>((const uint8_t *)d_base, 1, table, base_inf, tabws, 0, FB_ENTRIES);
             else k_g1_fb_build<<<grid_for(FB_ENTRIES), BLOCK, 0, st>>>((const uint8_t *)d_base, 1, table, base_inf, tabws, 0, FB_ENTRIES);
             rc = check_launch("k_fb_build");
+            profile_mark(g2 ? "k_g2_fb_build" : "k_g1_fb_build", st);
         }
     }
     if (rc == GPBC_OK) {
         if (g2) k_g2_fb_msm<<<grid_for(n), BLOCK, 0, st>>>(table, base_inf, 1, (const uint8_t *)d_scalars, n, 1, 1, (uint8_t *)d_out);
         else k_g1_fb_msm<<<grid_for(n), BLOCK, 0, st>>>(table, base_inf, 1, (const uint8_t *)d_scalars, n, 1, 1, (uint8_t *)d_out);
         rc = check_launch("k_fb_msm");
+        profile_mark(g2 ? "k_g2_fb_msm" : "k_g1_fb_msm", st);
     }
     (void)hipFreeAsync(mem, st);                                     // stream-ordered: released after the kernels above
     return rc;
@@ -194,6 +196,7 @@ static int scalar_mul_dev(bool g2, const void *d_bases, size_t nbase, const void
         if (g2) k_g2_scalar_mul<<<grid_for(m), BLOCK, 0, st>>>(b, shared, k, o, m, tabws);
         else k_g1_scalar_mul<<<grid_for(m), BLOCK, 0, st>>>(b, shared, k, o, m, tabws);
         TRY(check_launch(g2 ? "k_g2_scalar_mul" : "k_g1_scalar_mul"));
+        profile_mark(g2 ? "k_g2_scalar_mul" : "k_g1_scalar_mul", st);
     }
     return GPBC_OK;
 }
@@ -222,6 +225,7 @@ static int sum_dev(bool g2, const void *d_pts, size_t n, void *d_out, void *d_ws
         if (g2) k_g2_sum_level<<<grid_for(n_out), BLOCK, 0, (hipStream_t)stream>>>(in, n_in, out, n_out);
         else k_g1_sum_level<<<grid_for(n_out), BLOCK, 0, (hipStream_t)stream>>>(in, n_in, out, n_out);
         TRY(check_launch("k_sum_level"));
+        profile_mark(g2 ? "k_g2_sum_level" : "k_g1_sum_level", (hipStream_t)stream);
         if (n_out == 1) break;
         in = out; ws += n_out * pt; n_in = n_out;
     }
@@ -413,6 +417,7 @@ int gpbc_fixed_base_create_dev(int is_g2, const void *d_bases, size_t nbase, voi
             if (is_g2) k_g2_fb_build<<<grid_for(m), BLOCK, 0, st>>>((const uint8_t *)d_bases, nbase, h->table, h->base_inf, tabws, off, m);
             else k_g1_fb_build<<<grid_for(m), BLOCK, 0, st>>>((const uint8_t *)d_bases, nbase, h->table, h->base_inf, tabws, off, m);
             rc = check_launch("k_fb_build");
+            profile_mark(is_g2 ? "k_g2_fb_build" : "k_g1_fb_build", st);
         }
     }
     if (rc != GPBC_OK) { (void)hipFree(h->table); (void)hipFree(h->base_inf); delete h; return rc; }
@@ -473,6 +478,7 @@ int gpbc_fixed_base_msm_dev(const gpbc_fixed_base *h, const void *d_scalars, siz
     if (h->is_g2) k_g2_fb_msm<<<grid_for(lanes), BLOCK, 0, st>>>(h->table, h->base_inf, h->nbase, (const uint8_t *)d_scalars, n_msm, C, n_chunks, partial);
     else k_g1_fb_msm<<<grid_for(lanes), BLOCK, 0, st>>>(h->table, h->base_inf, h->nbase, (const uint8_t *)d_scalars, n_msm, C, n_chunks, partial);
     TRY(check_launch("k_fb_msm"));
+    profile_mark(h->is_g2 ? "k_g2_fb_msm" : "k_g1_fb_msm", st);
     // partials are chunk-major (partial[c * n_msm + m]); the strided sum kernel with n_out = c' * n_msm adds, for every m,
     // the chunks c' + i * c'' — so each launch divides the number of chunks by 16 until one row per sum is left
     const uint8_t *in = partial;
@@ -483,6 +489,7 @@ int gpbc_fixed_base_msm_dev(const gpbc_fixed_base *h, const void *d_scalars, siz
         if (h->is_g2) k_g2_sum_level<<<grid_for(c2 * n_msm), BLOCK, 0, st>>>(in, c * n_msm, out, c2 * n_msm);
         else k_g1_sum_level<<<grid_for(c2 * n_msm), BLOCK, 0, st>>>(in, c * n_msm, out, c2 * n_msm);
         TRY(check_launch("k_sum_level"));
+        profile_mark(h->is_g2 ? "k_g2_sum_level" : "k_g1_sum_level", st);
         in = out; ws += c2 * n_msm * pt; c = c2;
     }
     return GPBC_OK;

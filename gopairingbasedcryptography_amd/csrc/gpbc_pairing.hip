@@ -227,8 +227,10 @@ int gpbc_miller_loop_dev(const void *dP, const void *dQ, size_t n, void *d_f_out
         const uint8_t *p = (const uint8_t *)dP + off * GPBC_G1_BYTES, *q = (const uint8_t *)dQ + off * GPBC_G2_BYTES;
         k_miller_lines<<<grid_for(m), BLOCK, 0, st>>>(p, q, lines, m, chunk);
         TRY(check_launch("k_miller_lines"));
+        profile_mark("k_miller_lines", st);
         k_miller_accumulate<<<grid_for(2 * m), BLOCK, 0, st>>>(p, q, lines, (uint8_t *)d_f_out + off * GPBC_GT_BYTES, m, chunk);
         TRY(check_launch("k_miller_accumulate"));
+        profile_mark("k_miller_accumulate", st);
     }
     return GPBC_OK;
 }
@@ -237,6 +239,7 @@ int gpbc_final_exp_dev(const void *d_f, size_t n, void *d_gt_out, void *stream) 
     if (!d_f || !d_gt_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
     TRY(bind_device());
     k_final_exp<<<grid_for(2 * n), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_f, (uint8_t *)d_gt_out, n);
+    profile_mark("k_final_exp", (hipStream_t)stream);
     return check_launch("k_final_exp");
 }
 int gpbc_pair_batch_dev(const void *dP, const void *dQ, size_t n, void *d_gt_out, void *stream) {
@@ -253,6 +256,7 @@ int gpbc_multi_pair_dev(const void *dP, const void *dQ, const uint64_t *d_seg_of
     TRY(gpbc_miller_loop_dev(dP, dQ, n_pairs, d_workspace, stream));
     k_segment_product<<<grid_for(k), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_workspace, d_seg_off, (uint8_t *)d_gt_out, k, n_pairs);
     TRY(check_launch("k_segment_product"));
+    profile_mark("k_segment_product", (hipStream_t)stream);
     return gpbc_final_exp_dev(d_gt_out, k, d_gt_out, stream);
 }
 int gpbc_gt_exp_batch_dev(const void *d_x, const void *d_k, size_t n, void *d_out, void *stream) {
@@ -270,6 +274,7 @@ int gpbc_gt_exp_batch_dev(const void *d_x, const void *d_k, size_t n, void *d_ou
         k_gt_exp<<<grid_for(2 * m), BLOCK, 0, st>>>((const uint8_t *)d_x + off * GPBC_GT_BYTES, (const uint8_t *)d_k + off * GPBC_SCALAR_BYTES,
                                                     (uint8_t *)d_out + off * GPBC_GT_BYTES, m, tabws);
         TRY(check_launch("k_gt_exp"));
+        profile_mark("k_gt_exp", st);
     }
     return GPBC_OK;
 }
@@ -278,6 +283,7 @@ static int gt_binary_dev(int op, const void *a, const void *b, size_t n, void *o
     if (!a || (op != 2 && !b) || !out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
     TRY(bind_device());
     k_gt_binary<<<grid_for(n), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)a, (const uint8_t *)b, (uint8_t *)out, n, op);
+    profile_mark("k_gt_binary", (hipStream_t)stream);
     return check_launch("k_gt_binary");
 }
 int gpbc_gt_mul_batch_dev(const void *a, const void *b, size_t n, void *o, void *s) { return gt_binary_dev(0, a, b, n, o, s); }
@@ -375,6 +381,7 @@ static int multi_pair_core(const uint8_t *dP, const uint8_t *dQ, const uint64_t 
         if (dOk) {
             k_gt_is_one<<<grid_for(k), BLOCK, 0, st>>>(dG, dOk, k);
             TRY(check_launch("k_gt_is_one"));
+            profile_mark("k_gt_is_one", st);
         }
         HIP_TRY(hipStreamSynchronize(st));
         return GPBC_OK;
@@ -404,16 +411,20 @@ static int multi_pair_core(const uint8_t *dP, const uint8_t *dQ, const uint64_t 
             const uint64_t *co = (const uint64_t *)dChunkOff.p + cb;
             k_miller_lines_chunks<<<grid_for(n_slots), BLOCK, 0, st>>>(dP, dQ, lines, co, g, n_slots);
             TRY(check_launch("k_miller_lines_chunks"));
+            profile_mark("k_miller_lines_chunks", st);
             k_miller_accumulate_chunks<<<grid_for(2 * g), BLOCK, 0, st>>>(dP, dQ, lines, co, dPart.u8() + cb * GPBC_GT_BYTES, g, n_slots);
             TRY(check_launch("k_miller_accumulate_chunks"));
+            profile_mark("k_miller_accumulate_chunks", st);
         }
     }
     k_segment_product<<<grid_for(k), BLOCK, 0, st>>>(dPart.u8(), (const uint64_t *)dSegChunk.p, dG, k, n_chunks);
     TRY(check_launch("k_segment_product (segments)"));
+    profile_mark("k_segment_product", st);
     TRY(gpbc_final_exp_dev(dG, k, dG, st));
     if (dOk) {
         k_gt_is_one<<<grid_for(k), BLOCK, 0, st>>>(dG, dOk, k);
         TRY(check_launch("k_gt_is_one"));
+        profile_mark("k_gt_is_one", st);
     }
     HIP_TRY(hipStreamSynchronize(st));
     return GPBC_OK;
@@ -440,12 +451,16 @@ int gpbc_multi_pair_fixed_q_dev(const void *dP, const void *dQ, size_t m, size_t
     TRY(dSegChunk.upload(seg_chunk.data(), seg_chunk.size() * sizeof(uint64_t)));
     k_q_lines<<<grid_for(m), BLOCK, 0, st>>>((const uint8_t *)dQ, (int32_t *)dLines.p, m);
     TRY(check_launch("k_q_lines"));
+    profile_mark("k_q_lines", st);
     k_g1_internal<<<grid_for(m * k), BLOCK, 0, st>>>((const uint8_t *)dP, (int32_t *)dPint.p, m * k);
     TRY(check_launch("k_g1_internal"));
+    profile_mark("k_g1_internal", st);
     k_miller_accumulate_fixed_q<<<grid_for(2 * n_c * k), BLOCK, 0, st>>>((const int32_t *)dPint.p, (const uint8_t *)dQ, (const int32_t *)dLines.p, dPart.u8(), m, k, L, n_c);
     TRY(check_launch("k_miller_accumulate_fixed_q"));
+    profile_mark("k_miller_accumulate_fixed_q", st);
     k_segment_product<<<grid_for(k), BLOCK, 0, st>>>(dPart.u8(), (const uint64_t *)dSegChunk.p, (uint8_t *)d_gt_out, k, n_c * k);
     TRY(check_launch("k_segment_product"));
+    profile_mark("k_segment_product", st);
     TRY(gpbc_final_exp_dev(d_gt_out, k, d_gt_out, st));
     HIP_TRY(hipStreamSynchronize(st));
     return GPBC_OK;

@@ -240,6 +240,13 @@ int gpbc_g2_map_to_curve_batch(const void *u, size_t n, void *out);
 int gpbc_g1_map_to_curve_batch_dev(const void *d_u, size_t n, void *d_out, void *stream);
 int gpbc_g2_map_to_curve_batch_dev(const void *d_u, size_t n, void *d_out, void *stream);
 
+/* ---- per-kernel timing (measurement, bench.py) ---------------------------------------------------
+ * Between begin and end every kernel launch of the pairing / scalar-multiplication entries made on `stream` is bracketed by
+ * HIP events on that stream; end synchronises and returns, per kernel name (32-byte zero-padded rows), the summed duration
+ * in ms and the number of launches.  One measurement at a time per process. */
+int gpbc_profile_begin(void *stream);
+int gpbc_profile_end(char *names_out, double *total_ms_out, int *launches_out, int max_kernels, int *n_kernels_out);
+
 /* ---- field-level entry (kernel unit tests) ------------------------------------------------------ */
 int gpbc_fp_mul_batch(const void *a, const void *b, size_t n, void *out);
 

@@ -9,7 +9,7 @@ for PASS in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS
             "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_FLAT SQ_INSTS_LDS SQ_INST_CYCLES_VMEM SQ_IFETCH SQ_IFETCH_LEVEL GRBM_GUI_ACTIVE" \
             "SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT SQ_ACTIVE_INST_MISC SQ_WAIT_INST_LDS SQ_INSTS_SMEM"; do
   N=$(echo $PASS | cut -d' ' -f1)
-  timeout -k 10 300 rocprofv3 --pmc $PASS --output-format csv -d $R/gpurun_out/${TAG}_$N -- python3 $R/bench.py --batch $B --steps 1 --warmup 0 --no-secondary --cpu-sample 64 > $R/gpurun_out/${TAG}_$N.log 2>&1 || echo "pass $N failed"
+  timeout -k 10 300 rocprofv3 --pmc $PASS --output-format csv -d $R/gpurun_out/${TAG}_$N -- python3 $R/bench.py --batch $B --steps 1 --warmup 0 --no-secondary --no-cpu > $R/gpurun_out/${TAG}_$N.log 2>&1 || echo "pass $N failed"
 done
 python3 - <<PY
 import csv, glob, collections, os

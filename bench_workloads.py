@@ -42,7 +42,12 @@ def bench_scalars(tag, start, n):
 
 def _dev(engine, a, device):
     import torch
-    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    return torch.from_numpy(np.array(a, dtype=np.uint8, copy=True)).to(device)
+
+
+def _rows32(engine, a, device):
+    """n x 32 scalar rows on the device (2-D, so that slicing takes rows, not bytes)."""
+    return _dev(engine, a, device).reshape(-1, 32)
 
 
 def _mul_shared(engine, base, scalars_bytes, device, g2=False):
@@ -66,7 +71,7 @@ def aggregate(engine, n, device, start=0):
     acc = 0
     for a, b in zip(rho, x):
         acc += a * b
-    return {"pk": pk, "sigma": sigma, "rho": _dev(engine, rb, device), "H": np.asarray(H), "g1": g1, "sum_rho_x": acc % R_ORDER, "n": n}
+    return {"pk": pk, "sigma": sigma, "rho": _rows32(engine, rb, device), "H": np.asarray(H), "g1": g1, "sum_rho_x": acc % R_ORDER, "n": n}
 
 
 def aggregate_check(engine, A, B, H, g1):

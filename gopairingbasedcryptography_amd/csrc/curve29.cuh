@@ -193,7 +193,7 @@ template <> GPBC_INLINE Fe g_sel<Fe>(bool c, const Fe &a, const Fe &b) {
 #pragma unroll
     for (int i = 0; i < NL; i++) r.v[i] = c ? a.v[i] : b.v[i];
 #ifdef GPBC_BOUNDS
-    for (int i = 0; i < NL; i++) r.lb[i] = a.lb[i] > b.lb[i] ? a.lb[i] : b.lb[i];
+    for (int i = 0; i < NL; i++) { r.lo[i] = a.lo[i] < b.lo[i] ? a.lo[i] : b.lo[i]; r.hi[i] = a.hi[i] > b.hi[i] ? a.hi[i] : b.hi[i]; }
     r.vb = a.vb > b.vb ? a.vb : b.vb;
 #endif
     return r;

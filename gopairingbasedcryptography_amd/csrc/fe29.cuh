@@ -46,8 +46,8 @@ constexpr int32_t LMASK = (1 << LB) - 1;
 struct Fe {
     int32_t v[NL];
 #ifdef GPBC_BOUNDS
-    double lb[NL];   // |v[i]| <= lb[i]   (data-independent)
-    double vb;       // |value| <= vb * p
+    double lo[NL], hi[NL];   // lo[i] <= v[i] <= hi[i]   (data-independent signed intervals)
+    double vb;               // |value| <= vb * p
 #endif
 };
 
@@ -70,19 +70,36 @@ inline void bounds_fail(const char *what, double got, double lim) {
 }
 constexpr double P_OVER_2_232 = 3171407.0;     // ceil(p / 2^232): top-limb magnitude per unit of p
 constexpr double P_OVER_RP = 0.0059081;         // p / 2^261 (rounded up)
+inline double limb_mag(const Fe &r, int i) { return std::fmax(std::fabs(r.lo[i]), std::fabs(r.hi[i])); }
 inline void set_class_n(Fe &r, double vb) {     // limbs 0..7 masked to [0,2^29), top limb holds the rest
-    for (int i = 0; i < NL - 1; i++) r.lb[i] = (double)LMASK;
-    r.lb[NL - 1] = vb * P_OVER_2_232 + 2;
+    for (int i = 0; i < NL - 1; i++) { r.lo[i] = 0; r.hi[i] = (double)LMASK; }
+    r.hi[NL - 1] = vb * P_OVER_2_232 + 2;
+    r.lo[NL - 1] = -r.hi[NL - 1];
     r.vb = vb;
-    if (r.lb[NL - 1] > bound_stats().max_limb) bound_stats().max_limb = r.lb[NL - 1];
+    if (r.hi[NL - 1] > bound_stats().max_limb) bound_stats().max_limb = r.hi[NL - 1];
     if (vb > bound_stats().max_vb) bound_stats().max_vb = vb;
 }
 inline void check_limbs(const Fe &r, const char *what) {
     for (int i = 0; i < NL; i++) {
-        if (r.lb[i] >= 2147483648.0) bounds_fail(what, r.lb[i], 2147483648.0);
-        if (std::fabs((double)r.v[i]) > r.lb[i]) bounds_fail("tracked bound below actual value", std::fabs((double)r.v[i]), r.lb[i]);
-        if (r.lb[i] > bound_stats().max_limb) bound_stats().max_limb = r.lb[i];
+        if (r.hi[i] >= 2147483648.0) bounds_fail(what, r.hi[i], 2147483648.0);
+        if (r.lo[i] < -2147483648.0) bounds_fail(what, r.lo[i], -2147483648.0);
+        if ((double)r.v[i] > r.hi[i] || (double)r.v[i] < r.lo[i]) bounds_fail("tracked interval does not hold the actual value", (double)r.v[i], r.v[i] > r.hi[i] ? r.hi[i] : r.lo[i]);
+        if (limb_mag(r, i) > bound_stats().max_limb) bound_stats().max_limb = limb_mag(r, i);
     }
+}
+// interval of the column sums of a product sum_k x_k * y_k, limb intervals given: lo / hi of sum_{i+j=col} x_i y_j
+inline void prod_interval(double xl, double xh, double yl, double yh, double &pl, double &ph) {
+    double a = xl * yl, b = xl * yh, c = xh * yl, d = xh * yh;
+    pl = std::fmin(std::fmin(a, b), std::fmin(c, d));
+    ph = std::fmax(std::fmax(a, b), std::fmax(c, d));
+}
+inline void check_columns(double lo, double hi, const char *what) {
+    // + reduction terms m_i p_j (both factors in [0, 2^29): nine of them) and the running carry (|carry| < 2^35)
+    double top = hi + 9.0 * 536870912.0 * 536870912.0 + 34359738368.0, bot = lo - 34359738368.0;
+    if (top >= 9223372036854775808.0) bounds_fail(what, top, 9223372036854775808.0);
+    if (bot <= -9223372036854775808.0) bounds_fail(what, bot, -9223372036854775808.0);
+    double m = std::fmax(top, -bot);
+    if (m > bound_stats().max_col) bound_stats().max_col = m;
 }
 #endif
 
@@ -99,7 +116,7 @@ GPBC_INLINE Fe fe_zero() {
     Fe r;
 #pragma unroll
     for (int i = 0; i < NL; i++) r.v[i] = 0;
-    GPBC_B(for (int i = 0; i < NL; i++) r.lb[i] = 0; r.vb = 0;)
+    GPBC_B(for (int i = 0; i < NL; i++) { r.lo[i] = 0; r.hi[i] = 0; } r.vb = 0;)
     return r;
 }
 GPBC_INLINE Fe fe_one() { constexpr int32_t C[NL] = F29_ONE; return fe_const(C); }
@@ -109,21 +126,21 @@ GPBC_INLINE Fe fe_add(const Fe &a, const Fe &b) {
     Fe r;
 #pragma unroll
     for (int i = 0; i < NL; i++) r.v[i] = a.v[i] + b.v[i];
-    GPBC_B(for (int i = 0; i < NL; i++) r.lb[i] = a.lb[i] + b.lb[i]; r.vb = a.vb + b.vb; check_limbs(r, "fe_add limb");)
+    GPBC_B(for (int i = 0; i < NL; i++) { r.lo[i] = a.lo[i] + b.lo[i]; r.hi[i] = a.hi[i] + b.hi[i]; } r.vb = a.vb + b.vb; check_limbs(r, "fe_add limb");)
     return r;
 }
 GPBC_INLINE Fe fe_sub(const Fe &a, const Fe &b) {
     Fe r;
 #pragma unroll
     for (int i = 0; i < NL; i++) r.v[i] = a.v[i] - b.v[i];
-    GPBC_B(for (int i = 0; i < NL; i++) r.lb[i] = a.lb[i] + b.lb[i]; r.vb = a.vb + b.vb; check_limbs(r, "fe_sub limb");)
+    GPBC_B(for (int i = 0; i < NL; i++) { r.lo[i] = a.lo[i] - b.hi[i]; r.hi[i] = a.hi[i] - b.lo[i]; } r.vb = a.vb + b.vb; check_limbs(r, "fe_sub limb");)
     return r;
 }
 GPBC_INLINE Fe fe_neg(const Fe &a) {
     Fe r;
 #pragma unroll
     for (int i = 0; i < NL; i++) r.v[i] = -a.v[i];
-    GPBC_B(for (int i = 0; i < NL; i++) r.lb[i] = a.lb[i]; r.vb = a.vb;)
+    GPBC_B(for (int i = 0; i < NL; i++) { r.lo[i] = -a.hi[i]; r.hi[i] = -a.lo[i]; } r.vb = a.vb; check_limbs(r, "fe_neg limb");)
     return r;
 }
 GPBC_INLINE Fe fe_dbl(const Fe &a) { return fe_add(a, a); }
@@ -137,10 +154,11 @@ GPBC_INLINE Fe fe_norm(const Fe &a) {
     for (int i = 1; i < NL - 1; i++) r.v[i] = (a.v[i] & LMASK) + (a.v[i - 1] >> LB);
     r.v[NL - 1] = a.v[NL - 1] + (a.v[NL - 2] >> LB);
 #ifdef GPBC_BOUNDS
-    r.lb[0] = (double)LMASK;
-    // (x & M) is in [0, M]; (y >> 29) is in [-ceil(|y|/2^29), floor(|y|/2^29)]: the magnitude bound is the positive side
-    for (int i = 1; i < NL - 1; i++) r.lb[i] = (double)LMASK + std::floor(a.lb[i - 1] / 536870912.0);
-    r.lb[NL - 1] = a.lb[NL - 1] + std::ceil(a.lb[NL - 2] / 536870912.0);
+    r.lo[0] = 0; r.hi[0] = (double)LMASK;
+    // (x & M) is in [0, M]; (y >> 29) = floor(y / 2^29) is monotone in y
+    for (int i = 1; i < NL - 1; i++) { r.lo[i] = std::floor(a.lo[i - 1] / 536870912.0); r.hi[i] = (double)LMASK + std::floor(a.hi[i - 1] / 536870912.0); }
+    r.lo[NL - 1] = a.lo[NL - 1] + std::floor(a.lo[NL - 2] / 536870912.0);
+    r.hi[NL - 1] = a.hi[NL - 1] + std::floor(a.hi[NL - 2] / 536870912.0);
     r.vb = a.vb;
     bound_stats().norms++;
     check_limbs(r, "fe_norm limb");
@@ -155,20 +173,17 @@ template <bool TWO>
 GPBC_INLINE Fe fe_mul_core(const Fe &a, const Fe &b, const Fe &c, const Fe &d) {
 #ifdef GPBC_BOUNDS
     {
-        double worst = 0;
         for (int k = 0; k < 2 * NL - 1; k++) {
-            double s = 0;
+            double sl = 0, sh = 0;
             for (int i = 0; i < NL; i++) {
                 int j = k - i;
                 if (j < 0 || j >= NL) continue;
-                s += a.lb[i] * b.lb[j];
-                if (TWO) s += c.lb[i] * d.lb[j];
+                double pl, ph;
+                prod_interval(a.lo[i], a.hi[i], b.lo[j], b.hi[j], pl, ph); sl += pl; sh += ph;
+                if (TWO) { prod_interval(c.lo[i], c.hi[i], d.lo[j], d.hi[j], pl, ph); sl += pl; sh += ph; }
             }
-            if (s > worst) worst = s;
+            check_columns(sl, sh, "fe_mul column");
         }
-        double total = worst + 9.0 * 536870912.0 * 536870912.0 + 34359738368.0;   // + reduction terms + carry
-        if (total >= 9223372036854775808.0) bounds_fail("fe_mul column", total, 9223372036854775808.0);
-        if (total > bound_stats().max_col) bound_stats().max_col = total;
         bound_stats().muls++;
         if (TWO) bound_stats().muls2++;
     }
@@ -207,7 +222,7 @@ GPBC_INLINE Fe fe_mul_core(const Fe &a, const Fe &b, const Fe &c, const Fe &d) {
 #ifdef GPBC_BOUNDS
     double vb = (a.vb * b.vb + (TWO ? c.vb * d.vb : 0.0)) * P_OVER_RP + 1.0;
     set_class_n(r, vb);
-    if (r.lb[NL - 1] >= 268435456.0) bounds_fail("fe_mul output top limb", r.lb[NL - 1], 268435456.0);
+    if (r.hi[NL - 1] >= 268435456.0) bounds_fail("fe_mul output top limb", r.hi[NL - 1], 268435456.0);
     check_limbs(r, "fe_mul output");
 #endif
     return r;
@@ -382,16 +397,12 @@ GPBC_INLINE Fe fe_mul2(const Fe &a, const Fe &b, const Fe &c, const Fe &d) { ret
 GPBC_INLINE Fe fe_sqr_core(const Fe &a) {
 #ifdef GPBC_BOUNDS
     {
-        double worst = 0;
         for (int k = 0; k < 2 * NL - 1; k++) {
-            double s = 0;
-            for (int i = 0; i < NL; i++) { int j = k - i; if (j >= 0 && j < NL) s += a.lb[i] * a.lb[j]; }
-            if (s > worst) worst = s;
+            double sl = 0, sh = 0;
+            for (int i = 0; i < NL; i++) { int j = k - i; if (j < 0 || j >= NL) continue; double pl, ph; prod_interval(a.lo[i], a.hi[i], a.lo[j], a.hi[j], pl, ph); sl += pl; sh += ph; }
+            check_columns(sl, sh, "fe_sqr column");
         }
-        double total = worst + 9.0 * 536870912.0 * 536870912.0 + 34359738368.0;
-        if (total >= 9223372036854775808.0) bounds_fail("fe_sqr column", total, 9223372036854775808.0);
-        for (int i = 0; i < NL; i++) if (2 * a.lb[i] >= 2147483648.0) bounds_fail("fe_sqr doubled limb", 2 * a.lb[i], 2147483648.0);
-        if (total > bound_stats().max_col) bound_stats().max_col = total;
+        for (int i = 0; i < NL; i++) if (2 * limb_mag(a, i) >= 2147483648.0) bounds_fail("fe_sqr doubled limb", 2 * limb_mag(a, i), 2147483648.0);
         bound_stats().muls++;
     }
 #endif
@@ -425,7 +436,7 @@ GPBC_INLINE Fe fe_sqr_core(const Fe &a) {
     r.v[NL - 1] = (int32_t)acc;
 #ifdef GPBC_BOUNDS
     set_class_n(r, a.vb * a.vb * P_OVER_RP + 1.0);
-    if (r.lb[NL - 1] >= 268435456.0) bounds_fail("fe_sqr output top limb", r.lb[NL - 1], 268435456.0);
+    if (r.hi[NL - 1] >= 268435456.0) bounds_fail("fe_sqr output top limb", r.hi[NL - 1], 268435456.0);
     check_limbs(r, "fe_sqr output");
 #endif
     return r;
@@ -447,9 +458,10 @@ GPBC_INLINE Fe fe_mul8_norm(const Fe &a) {
     for (int i = 1; i < NL - 1; i++) r.v[i] = ((a.v[i] & M26) << 3) + (a.v[i - 1] >> (LB - 3));
     r.v[NL - 1] = a.v[NL - 1] * 8 + (a.v[NL - 2] >> (LB - 3));
 #ifdef GPBC_BOUNDS
-    r.lb[0] = (double)LMASK;
-    for (int i = 1; i < NL - 1; i++) r.lb[i] = (double)(LMASK - 7) + std::floor(a.lb[i - 1] / 67108864.0);
-    r.lb[NL - 1] = a.lb[NL - 1] * 8 + std::ceil(a.lb[NL - 2] / 67108864.0);
+    r.lo[0] = 0; r.hi[0] = (double)(LMASK - 7);
+    for (int i = 1; i < NL - 1; i++) { r.lo[i] = std::floor(a.lo[i - 1] / 67108864.0); r.hi[i] = (double)(LMASK - 7) + std::floor(a.hi[i - 1] / 67108864.0); }
+    r.lo[NL - 1] = a.lo[NL - 1] * 8 + std::floor(a.lo[NL - 2] / 67108864.0);
+    r.hi[NL - 1] = a.hi[NL - 1] * 8 + std::floor(a.hi[NL - 2] / 67108864.0);
     r.vb = a.vb * 8;
     check_limbs(r, "fe_mul8_norm limb");
 #endif
@@ -466,9 +478,9 @@ GPBC_INLINE Fe fe_halve(const Fe &a) {
     for (int i = 0; i < NL - 1; i++) r.v[i] = (t[i] >> 1) + ((t[i + 1] & 1) << (LB - 1));
     r.v[NL - 1] = t[NL - 1] >> 1;
 #ifdef GPBC_BOUNDS
-    for (int i = 0; i < NL; i++) if (a.lb[i] + (double)LMASK >= 2147483648.0) bounds_fail("fe_halve input limb", a.lb[i], 2147483648.0 - LMASK);
-    for (int i = 0; i < NL - 1; i++) r.lb[i] = (a.lb[i] + (double)LMASK) / 2 + 1 + 268435456.0;
-    r.lb[NL - 1] = (a.lb[NL - 1] + (double)f29_p(NL - 1)) / 2 + 1;
+    for (int i = 0; i < NL; i++) if (a.hi[i] + (double)LMASK >= 2147483648.0) bounds_fail("fe_halve input limb", a.hi[i], 2147483648.0 - LMASK);
+    for (int i = 0; i < NL - 1; i++) { r.lo[i] = std::floor(a.lo[i] / 2); r.hi[i] = std::floor((a.hi[i] + (double)f29_p(i)) / 2) + 268435456.0; }
+    r.lo[NL - 1] = std::floor(a.lo[NL - 1] / 2); r.hi[NL - 1] = std::floor((a.hi[NL - 1] + (double)f29_p(NL - 1)) / 2);
     r.vb = (a.vb + 1) / 2;
     check_limbs(r, "fe_halve limb");
 #endif
@@ -488,7 +500,7 @@ static const int32_t F29_KP[513][12] = F29_KP_ROWS;
 GPBC_INLINE Fe fe_reduce(const Fe &a) {
 #ifdef GPBC_BOUNDS
     if (a.vb >= 256.0) bounds_fail("fe_reduce input value", a.vb, 256.0);
-    for (int i = 0; i < NL - 1; i++) if (a.lb[i] > 536870912.0 + 1024) bounds_fail("fe_reduce input limb (normalise first)", a.lb[i], 536870912.0 + 1024);
+    for (int i = 0; i < NL - 1; i++) if (limb_mag(a, i) > 536870912.0 + 1024) bounds_fail("fe_reduce input limb (normalise first)", limb_mag(a, i), 536870912.0 + 1024);
 #endif
     constexpr int32_t P8 = f29_p(NL - 1);
     int32_t k = (int32_t)rintf((float)a.v[NL - 1] * (1.0f / (float)P8));
@@ -498,9 +510,8 @@ GPBC_INLINE Fe fe_reduce(const Fe &a) {
 #pragma unroll
     for (int i = 0; i < NL; i++) r.v[i] = a.v[i] - row[i];
 #ifdef GPBC_BOUNDS
-    for (int i = 0; i < NL - 1; i++) r.lb[i] = a.lb[i] + 257;       // a row limb lies in [0, 2^29): it never adds magnitude beyond the input's
-    for (int i = 0; i < NL - 1; i++) if (r.lb[i] < 536870912.0 + 257) r.lb[i] = 536870912.0 + 257;
-    r.lb[NL - 1] = (double)P8 / 2 + 270;
+    for (int i = 0; i < NL - 1; i++) { r.lo[i] = a.lo[i] - (double)LMASK - 257; r.hi[i] = a.hi[i] + 257; }   // minus a row limb in [0, 2^29) (+-256 for the arithmetic form's carries)
+    r.hi[NL - 1] = (double)P8 / 2 + 270; r.lo[NL - 1] = -r.hi[NL - 1];
     r.vb = 0.51;
     bound_stats().reduces++;
     check_limbs(r, "fe_reduce limb");
@@ -514,7 +525,7 @@ GPBC_INLINE Fe fe_reduce(const Fe &a) {
 GPBC_INLINE Fe fe_reduce_arith(const Fe &a) {
 #ifdef GPBC_BOUNDS
     if (a.vb >= 256.0) bounds_fail("fe_reduce input value", a.vb, 256.0);
-    for (int i = 0; i < NL - 1; i++) if (a.lb[i] > 536870912.0 + 1024) bounds_fail("fe_reduce input limb (normalise first)", a.lb[i], 536870912.0 + 1024);
+    for (int i = 0; i < NL - 1; i++) if (limb_mag(a, i) > 536870912.0 + 1024) bounds_fail("fe_reduce input limb (normalise first)", limb_mag(a, i), 536870912.0 + 1024);
 #endif
     constexpr int32_t P8 = f29_p(NL - 1);
     int32_t k = (int32_t)rintf((float)a.v[NL - 1] * (1.0f / (float)P8));
@@ -528,9 +539,8 @@ GPBC_INLINE Fe fe_reduce_arith(const Fe &a) {
         hi_prev = hi;
     }
 #ifdef GPBC_BOUNDS
-    for (int i = 0; i < NL - 1; i++) r.lb[i] = a.lb[i] + 257;       // lo in [0,2^29) never adds magnitude beyond the input's; hi within +-256
-    for (int i = 0; i < NL - 1; i++) if (r.lb[i] < 536870912.0 + 257) r.lb[i] = 536870912.0 + 257;
-    r.lb[NL - 1] = (double)P8 / 2 + 270;
+    for (int i = 0; i < NL - 1; i++) { r.lo[i] = a.lo[i] - (double)LMASK - 257; r.hi[i] = a.hi[i] + 257; }   // minus a row limb in [0, 2^29) (+-256 for the arithmetic form's carries)
+    r.hi[NL - 1] = (double)P8 / 2 + 270; r.lo[NL - 1] = -r.hi[NL - 1];
     r.vb = 0.51;
     bound_stats().reduces++;
     check_limbs(r, "fe_reduce limb");
@@ -572,7 +582,7 @@ GPBC_INLINE Fe fe_canonical(const Fe &a) {
 GPBC_INLINE bool fe_is_zero(const Fe &a) {
 #ifdef GPBC_BOUNDS
     if (a.vb >= 128.0) bounds_fail("fe_is_zero input value", a.vb, 128.0);
-    for (int i = 0; i < NL - 1; i++) if (a.lb[i] > 536870912.0 + 64) bounds_fail("fe_is_zero input limb (normalise first)", a.lb[i], 536870912.0 + 64);
+    for (int i = 0; i < NL - 1; i++) if (limb_mag(a, i) > 536870912.0 + 64) bounds_fail("fe_is_zero input limb (normalise first)", limb_mag(a, i), 536870912.0 + 64);
 #endif
     constexpr int32_t P8 = f29_p(NL - 1);
     int32_t top = a.v[NL - 1];

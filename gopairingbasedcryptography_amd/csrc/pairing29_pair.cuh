@@ -143,7 +143,13 @@ GPBC_INLINE F6 f6_row_load(const int32_t *row) {
     for (int e = 0; e < 6; e++) {
 #pragma unroll
         for (int i = 0; i < NL; i++) fe[e]->v[i] = w[e * NL + i];
-        GPBC_B(set_class_n(*fe[e], 1.5);)          // table entries are outputs of f12p_mul (value-reduced, normalised)
+#ifdef GPBC_BOUNDS
+        // table entries are one, the base (normalised, limbs in [0, 2^29)) or outputs of f12p_mul (value-reduced: limbs
+        // within +-(2^29 + 2^10), |value| < 0.51 p): the union of those intervals
+        set_class_n(*fe[e], 1.5);
+        for (int i = 0; i < NL - 1; i++) { fe[e]->lo[i] = -((double)LMASK + 1024); fe[e]->hi[i] = (double)LMASK + 1024; }
+        check_limbs(*fe[e], "GT.Exp table entry");
+#endif
     }
     return v;
 }

@@ -142,12 +142,15 @@ GPBC_INLINE F6 f6_sqr(const F6 &x) {   // CH-SQR2
 }
 GPBC_INLINE F6 f6_mul_f2(const F6 &x, const F2 &k) { return F6{f2_mul(x.b0, k), f2_mul(x.b1, k), f2_mul(x.b2, k)}; }
 // x * (c0 + c1 v); s01 = norm(c0 + c1) supplied by the caller (shared between the two uses in the sparse F12 product)
-template <bool RX> GPBC_INLINE F6 f6_mul_01_t(const F6 &x, const F2 &c0, const F2 &c1, const F2 &s01) {
+// NORM01 = false leaves the first two output coefficients un-normalised (limbs within (-2^30, 2^30]): for callers that only
+// add them to something and normalise the sum; the third one is normalised either way (a multiplication by v sends it
+// through the xi product, whose eightfold term needs the headroom)
+template <bool RX, bool NORM01 = true> GPBC_INLINE F6 f6_mul_01_t(const F6 &x, const F2 &c0, const F2 &c1, const F2 &s01) {
     F2 a = f2_mul(x.b0, c0), b = f2_mul(x.b1, c1);
     F2 t0 = f2_add(f2_mul_xi_t<RX>(f2_norm(f2_sub(f2_mul(f2_norm(f2_add(x.b1, x.b2)), c1), b))), a);
     F2 t1 = f2_sub(f2_sub(f2_mul(f2_norm(f2_add(x.b0, x.b1)), s01), a), b);
     F2 t2 = f2_add(f2_sub(f2_mul(f2_norm(f2_add(x.b0, x.b2)), c0), a), b);
-    return F6{f2_norm(t0), f2_norm(t1), f2_norm(t2)};
+    return F6{NORM01 ? f2_norm(t0) : t0, NORM01 ? f2_norm(t1) : t1, f2_norm(t2)};
 }
 GPBC_INLINE F6 f6_mul_01(const F6 &x, const F2 &c0, const F2 &c1, const F2 &s01) { return f6_mul_01_t<true>(x, c0, c1, s01); }
 GPBC_INLINE F6 f6_inv(const F6 &x) {

@@ -24,7 +24,7 @@ GPBC_INLINE Fe fe_sel(bool c, const Fe &a, const Fe &b) {
 #pragma unroll
     for (int i = 0; i < NL; i++) r.v[i] = c ? a.v[i] : b.v[i];
 #ifdef GPBC_BOUNDS
-    for (int i = 0; i < NL; i++) r.lb[i] = a.lb[i] > b.lb[i] ? a.lb[i] : b.lb[i];   // bound must hold for either lane
+    for (int i = 0; i < NL; i++) { r.lo[i] = a.lo[i] < b.lo[i] ? a.lo[i] : b.lo[i]; r.hi[i] = a.hi[i] > b.hi[i] ? a.hi[i] : b.hi[i]; }   // must hold for either lane
     r.vb = a.vb > b.vb ? a.vb : b.vb;
 #endif
     return r;
@@ -51,8 +51,36 @@ struct PairDpp {
     }
     __device__ __forceinline__ F2 swap(const F2 &a) const { return F2{swap(a.a0), swap(a.a1)}; }
     __device__ __forceinline__ F6 swap(const F6 &a) const { return F6{swap(a.b0), swap(a.b1), swap(a.b2)}; }
+    // a on the odd lane, -a on the even lane: ONE multiplication by the lane's +-1 per limb instead of a negation and a select
+    __device__ __forceinline__ Fe sgn(const Fe &a) const {
+        int32_t s = odd ? 1 : -1;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm("" : "+v"(s));                 // keep it a multiplication (the optimiser would turn it back into negate + select)
+#endif
+        Fe r;
+#pragma unroll
+        for (int i = 0; i < NL; i++) r.v[i] = a.v[i] * s;
+        return r;
+    }
+    // a + swap(b) in one instruction per limb (v_add_u32_dpp: the lane swap rides on the addition's first operand)
+    __device__ __forceinline__ Fe add_swap(const Fe &a, const Fe &b) const {
+        Fe r;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int i = 0; i < NL; i++)
+            asm("v_add_u32_dpp %0, %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(r.v[i]) : "v"(b.v[i]), "v"(a.v[i]));
+#else
+        r = a;
+#endif
+        return r;
+    }
 };
 #endif
+// policy helpers on the tower types; the host policy of tools/bounds_check.cpp provides the same two Fe primitives
+template <class X> GPBC_INLINE F2 f2p_sgn(const X &x, const F2 &a) { return F2{x.sgn(a.a0), x.sgn(a.a1)}; }
+template <class X> GPBC_INLINE F6 f6p_sgn(const X &x, const F6 &a) { return F6{f2p_sgn(x, a.b0), f2p_sgn(x, a.b1), f2p_sgn(x, a.b2)}; }
+template <class X> GPBC_INLINE F2 f2p_add_swap(const X &x, const F2 &a, const F2 &b) { return F2{x.add_swap(a.a0, b.a0), x.add_swap(a.a1, b.a1)}; }
+template <class X> GPBC_INLINE F6 f6p_add_swap(const X &x, const F6 &a, const F6 &b) { return F6{f2p_add_swap(x, a.b0, b.b0), f2p_add_swap(x, a.b1, b.b1), f2p_add_swap(x, a.b2, b.b2)}; }
 
 // (C0 on even, C1 on odd) <- one()
 template <class X> GPBC_INLINE F6 f12p_one(const X &x) { return f6_sel(x.odd, F6{f2_zero(), f2_zero(), f2_zero()}, F6{f2_one(), f2_zero(), f2_zero()}); }
@@ -76,7 +104,7 @@ template <class X> GPBC_INLINE F6 f12p_sqr(const X &x, const F6 &h) {
 template <class X> GPBC_INLINE F6 f12p_mul_034(const X &x, const F6 &h, const F2 &c0, const F2 &c3, const F2 &c4) {
     F2 s34 = f2_norm(f2_add(c3, c4));
     F6 r0 = f6_mul_f2(h, c0);
-    F6 r1 = f6_mul_01_t<false>(h, c3, c4, s34);
+    F6 r1 = f6_mul_01_t<false, false>(h, c3, c4, s34);       // b0, b1 un-normalised: they only enter the sum below
     F6 p1 = x.swap(r1);
     F6 add = f6_sel(x.odd, p1, f6_mul_v_t<false>(p1));
     return f6_reduce_arith(f6_norm(f6_add(r0, add)));                    // the one value reduction of this step (no table loads
@@ -87,8 +115,8 @@ template <class X> GPBC_INLINE F6 f12p_mul_034(const X &x, const F6 &h, const F2
 // diagonal F2 products, the odd lane its three cross products.
 template <class X> GPBC_INLINE F6 f12p_mul(const X &x, const F6 &hx, const F6 &hy) {
     F6 t = f6_mul_t<false>(hx, hy);                          // even: t0 = a0 b0, odd: t1 = a1 b1
-    F6 sx = f6_norm(f6_add(hx, x.swap(hx)));
-    F6 sy = f6_norm(f6_add(hy, x.swap(hy)));
+    F6 sx = f6_norm(f6p_add_swap(x, hx, hx));               // own half + partner's half, swap fused into the addition
+    F6 sy = f6_norm(f6p_add_swap(x, hy, hy));
     // three F2 products per lane of sx * sy
     F2 xa = f2_sel(x.odd, f2_norm(f2_add(sx.b1, sx.b2)), sx.b0), ya = f2_sel(x.odd, f2_norm(f2_add(sy.b1, sy.b2)), sy.b0);
     F2 xb = f2_sel(x.odd, f2_norm(f2_add(sx.b0, sx.b1)), sx.b1), yb = f2_sel(x.odd, f2_norm(f2_add(sy.b0, sy.b1)), sy.b1);
@@ -102,7 +130,9 @@ template <class X> GPBC_INLINE F6 f12p_mul(const X &x, const F6 &hx, const F6 &h
     F2 m0 = f2_add(xi1, dg.b0);
     F2 m1 = f2_add(f2_norm(f2_sub(f2_sub(cr.b1, dg.b0), dg.b1)), f2_mul_xi_nn(dg.b2));
     F2 m2 = f2_add(f2_sub(f2_sub(cr.b2, dg.b0), dg.b2), dg.b1);
-    F6 m{f2_norm(m0), f2_norm(m1), f2_norm(m2)};              // (a0+a1)(b0+b1): meaningful on the odd lane
+    F6 m{m0, m1, f2_norm(m2)};                                // (a0+a1)(b0+b1): meaningful on the odd lane.  m0, m1 are sums of two
+                                                              // normalised values (limbs within [0, 2^30]) and enter the three-term
+                                                              // difference below un-normalised; m2 reaches -2^30 and would not fit
     F6 even_out = f6_add(t, F6{xi1, pt.b0, pt.b1});           // t0 + v t1
     F6 odd_out = f6_sub(f6_sub(m, pt), t);                    // m - t0 - t1
     return f6_reduce(f6_norm(f6_sel(x.odd, odd_out, even_out)));
@@ -117,24 +147,27 @@ template <class X> GPBC_INLINE F6 f12p_mul(const X &x, const F6 &hx, const F6 &h
 template <bool REDUCE, class X> GPBC_INLINE F6 f12p_cyclo_sqr(const X &x, const F6 &h) {
     F6 p = x.swap(h);
     F2 q0 = f2_sqr(h.b0), q1 = f2_sqr(h.b1), q2 = f2_sqr(h.b2);        // even: t1,t5,t2   odd: t3,t0,t4
-    F2 sa = f2_sqr_n(f2_add(f2_sel(x.odd, h.b2, h.b0), p.b1));           // even: s6   odd: s8
+    F2 sa = f2_sqr_n(f2p_add_swap(x, f2_sel(x.odd, h.b2, h.b0), h.b1));   // even: s6   odd: s8   (own + partner's b1)
     // s7 = (C0.b2 + C1.b0)^2 is the ninth squaring: its two Fe products are shared, the even lane forms the real part
     // (u0+u1)(u0-u1), the odd lane the imaginary part 2 u0 u1, so each lane carries 4.5 squarings.
     F2 u = f2_norm(f2_add(f2_sel(x.odd, p.b2, h.b2), f2_sel(x.odd, h.b0, p.b0)));        // C0.b2 + C1.b0 on both lanes
-    Fe half = fe_mul(fe_sel(x.odd, fe_dbl(u.a0), fe_norm(fe_add(u.a0, u.a1))), fe_sel(x.odd, u.a1, fe_norm(fe_sub(u.a0, u.a1))));
+    // (a single Fe product has nine limb products per column, not eighteen: one operand may carry limbs up to 2^30, so the
+    // sum u0 + u1 goes in as it is and the difference — limbs within +-2^29 — needs no normalisation either)
+    Fe half = fe_mul(fe_sel(x.odd, fe_dbl(u.a0), fe_add(u.a0, u.a1)), fe_sel(x.odd, u.a1, fe_sub(u.a0, u.a1)));
     Fe phalf = x.swap(half);
     F2 sb{fe_sel(x.odd, phalf, half), fe_sel(x.odd, half, phalf)};        // s7 on both lanes
     F2 psa = x.swap(sa), pq0 = x.swap(q0), pq2 = x.swap(q2);
-    // (the xi products are only normalised here: the value reduction happens once, on the outputs)
-    F2 A = f2_norm(f2_mul_xi(q2));                                        // even: xi t2   odd: xi t4
-    F2 B = f2_norm(f2_mul_xi(f2_sel(x.odd, q1, f2_norm(f2_sub(f2_sub(psa, pq2), q1)))));   // even: xi (s8-t4-t5)   odd: xi t0
+    // (the xi products travel UN-normalised — limbs within (-2^29, 2^30) — and are normalised once, inside the sums they
+    // enter; the value reduction happens once, on the outputs)
+    F2 A = f2_mul_xi(q2);                                                 // even: xi t2   odd: xi t4
+    F2 B = f2_mul_xi(f2_sel(x.odd, q1, f2_norm(f2_sub(f2_sub(psa, pq2), q1))));          // even: xi (s8-t4-t5)   odd: xi t0
     F2 pA = x.swap(A), pB = x.swap(B);
     const F2 &psb = sb;
-    F2 tt0 = f2_sel(x.odd, pB, f2_norm(f2_add(pB, q0)));
+    F2 tt0 = f2_norm(f2_sel(x.odd, pB, f2_add(pB, q0)));
     F2 tt1 = f2_norm(f2_sel(x.odd, f2_sub(f2_sub(psa, q1), pq0), f2_add(A, pq0)));       // select first: one normalisation, not two
     F2 tt2 = f2_norm(f2_sel(x.odd, f2_sub(f2_sub(psb, pq2), q0), f2_add(pA, q1)));
     // out = 3 tt -+ 2 own coefficient  (minus on the even lane, plus on the odd lane)
-    F6 sgn = f6_sel(x.odd, h, f6_neg(h));
+    F6 sgn = f6p_sgn(x, h);
     F6 r{f2_norm(f2_add(f2_dbl(f2_norm(f2_add(tt0, sgn.b0))), tt0)),
          f2_norm(f2_add(f2_dbl(f2_norm(f2_add(tt1, sgn.b1))), tt1)),
          f2_norm(f2_add(f2_dbl(f2_norm(f2_add(tt2, sgn.b2))), tt2))};

@@ -42,6 +42,8 @@ struct PairHost {
     Fe swap(const Fe &a) const { return rv->exchange<Fe>(odd, a); }
     F2 swap(const F2 &a) const { return rv->exchange<F2>(odd, a); }
     F6 swap(const F6 &a) const { return rv->exchange<F6>(odd, a); }
+    Fe sgn(const Fe &a) const { return odd ? a : fe_neg(a); }                       // device: one multiplication by the lane's +-1
+    Fe add_swap(const Fe &a, const Fe &b) const { return fe_add(a, swap(b)); }       // device: v_add_u32_dpp
 };
 static std::mutex g_stats_mu;
 static BoundStats g_stats_total;

@@ -88,7 +88,7 @@ GPBC_INLINE F2 f2_mul_xi_nn(const F2 &x) { return f2_norm(f2_mul_xi(x)); }      
 template <bool RX> GPBC_INLINE F2 f2_mul_xi_t(const F2 &x) { return RX ? f2_mul_xi_n(x) : f2_mul_xi_nn(x); }
 GPBC_INLINE F2 f2_mul8_norm(const F2 &x) { return F2{fe_mul8_norm(x.a0), fe_mul8_norm(x.a1)}; }
 GPBC_INLINE F2 f2_inv(const F2 &x) {
-    Fe n = fe_inv(fe_norm(fe_add(fe_sqr(x.a0), fe_sqr(x.a1))));
+    Fe n = fe_inv(fe_add(fe_sqr(x.a0), fe_sqr(x.a1)));       // fe_inv starts with a product by one: limbs up to 2^30 fit
     return F2{fe_mul(x.a0, n), fe_neg(fe_mul(x.a1, n))};
 }
 GPBC_INLINE F2 f2_load(const uint8_t *p) { return F2{fe_load(p), fe_load(p + 32)}; }
@@ -124,7 +124,7 @@ template <bool RX> GPBC_INLINE F6 f6_mul_t(const F6 &x, const F6 &y) {
     F2 m01 = f2_mul_nn(f2_add(x.b0, x.b1), f2_add(y.b0, y.b1));
     F2 m02 = f2_mul_nn(f2_add(x.b0, x.b2), f2_add(y.b0, y.b2));
     F2 c0 = f2_add(f2_mul_xi_t<RX>(f2_norm(f2_sub(f2_sub(m12, t1), t2))), t0);
-    F2 c1 = f2_add(f2_norm(f2_sub(f2_sub(m01, t0), t1)), f2_mul_xi_t<RX>(t2));
+    F2 c1 = f2_add(f2_sub(f2_sub(m01, t0), t1), f2_mul_xi_t<RX>(t2));        // within (-2^30, 2^30 + 2^29): one normalisation, below
     F2 c2 = f2_add(f2_sub(f2_sub(m02, t0), t2), t1);
     return F6{f2_norm(c0), f2_norm(c1), f2_norm(c2)};
 }
@@ -137,26 +137,27 @@ GPBC_INLINE F6 f6_sqr(const F6 &x) {   // CH-SQR2
     F2 s4 = f2_sqr(x.b2);
     F2 c0 = f2_add(s0, f2_mul_xi_n(f2_norm(f2_dbl(m12))));
     F2 c1 = f2_add(f2_dbl(m01), f2_mul_xi_n(s4));
-    F2 c2 = f2_add(f2_norm(f2_dbl(f2_add(m01, m12))), f2_norm(f2_sub(f2_sub(s2, s0), s4)));
-    return F6{f2_norm(c0), f2_norm(c1), f2_norm(c2)};
+    F2 c2 = f2_add(f2_norm(f2_dbl(f2_add(m01, m12))), f2_sub(f2_sub(s2, s0), s4));
+    return F6{c0, f2_norm(c1), f2_norm(c2)};                  // c0 = s0 + a reduced xi product: already within [-2^29, 2^30]
 }
 GPBC_INLINE F6 f6_mul_f2(const F6 &x, const F2 &k) { return F6{f2_mul(x.b0, k), f2_mul(x.b1, k), f2_mul(x.b2, k)}; }
 // x * (c0 + c1 v); s01 = norm(c0 + c1) supplied by the caller (shared between the two uses in the sparse F12 product)
-// NORM01 = false leaves the first two output coefficients un-normalised (limbs within (-2^30, 2^30]): for callers that only
-// add them to something and normalise the sum; the third one is normalised either way (a multiplication by v sends it
-// through the xi product, whose eightfold term needs the headroom)
+// NORM01 = false leaves the first output coefficient un-normalised as well (limbs within (-2^30, 2^30]): for callers that only
+// add it to something and normalise the sum; the second one is never normalised here, the third one always (a multiplication
+// by v sends it through the xi product, whose eightfold term needs the headroom).  Which normalisations are redundant was
+// found by dropping them one at a time under the signed-interval bounds harness (tools/prune_norms.py).
 template <bool RX, bool NORM01 = true> GPBC_INLINE F6 f6_mul_01_t(const F6 &x, const F2 &c0, const F2 &c1, const F2 &s01) {
     F2 a = f2_mul(x.b0, c0), b = f2_mul(x.b1, c1);
-    F2 t0 = f2_add(f2_mul_xi_t<RX>(f2_norm(f2_sub(f2_mul(f2_norm(f2_add(x.b1, x.b2)), c1), b))), a);
+    F2 t0 = f2_add(f2_mul_xi_t<RX>(f2_sub(f2_mul(f2_norm(f2_add(x.b1, x.b2)), c1), b)), a);      // the xi product re-splits its eightfold term itself
     F2 t1 = f2_sub(f2_sub(f2_mul(f2_norm(f2_add(x.b0, x.b1)), s01), a), b);
     F2 t2 = f2_add(f2_sub(f2_mul(f2_norm(f2_add(x.b0, x.b2)), c0), a), b);
-    return F6{NORM01 ? f2_norm(t0) : t0, NORM01 ? f2_norm(t1) : t1, f2_norm(t2)};
+    return F6{NORM01 ? f2_norm(t0) : t0, t1, f2_norm(t2)};    // t1 = m - a - b stays within (-2^30, 2^29): every caller only adds it
 }
 GPBC_INLINE F6 f6_mul_01(const F6 &x, const F2 &c0, const F2 &c1, const F2 &s01) { return f6_mul_01_t<true>(x, c0, c1, s01); }
 GPBC_INLINE F6 f6_inv(const F6 &x) {
     F2 t0 = f2_norm(f2_sub(f2_sqr(x.b0), f2_mul_xi_n(f2_mul(x.b1, x.b2))));
     F2 t1 = f2_norm(f2_sub(f2_mul_xi_n(f2_sqr(x.b2)), f2_mul(x.b0, x.b1)));
-    F2 t2 = f2_norm(f2_sub(f2_sqr(x.b1), f2_mul(x.b0, x.b2)));
+    F2 t2 = f2_sub(f2_sqr(x.b1), f2_mul(x.b0, x.b2));
     F2 inner = f2_norm(f2_add(f2_mul(x.b2, t1), f2_mul(x.b1, t2)));
     F2 d = f2_norm(f2_add(f2_mul(x.b0, t0), f2_mul_xi_n(inner)));
     d = f2_inv(d);
@@ -207,9 +208,9 @@ template <bool REDUCE> GPBC_INLINE F2 cyclo_out(const F2 &t, const F2 &x, bool p
 }
 template <bool REDUCE> GPBC_INLINE F12 f12_cyclo_sqr_t(const F12 &x) {
     F2 t0 = f2_sqr(x.c1.b1), t1 = f2_sqr(x.c0.b0);
-    F2 t6 = f2_norm(f2_sub(f2_sub(f2_sqr_n(f2_add(x.c1.b1, x.c0.b0)), t0), t1));
+    F2 t6 = f2_sub(f2_sub(f2_sqr_n(f2_add(x.c1.b1, x.c0.b0)), t0), t1);       // (-2^30, 2^29): cyclo_out normalises the sum it enters
     F2 t2 = f2_sqr(x.c0.b2), t3 = f2_sqr(x.c1.b0);
-    F2 t7 = f2_norm(f2_sub(f2_sub(f2_sqr_n(f2_add(x.c0.b2, x.c1.b0)), t2), t3));
+    F2 t7 = f2_sub(f2_sub(f2_sqr_n(f2_add(x.c0.b2, x.c1.b0)), t2), t3);
     F2 t4 = f2_sqr(x.c1.b2), t5 = f2_sqr(x.c0.b1);
     F2 t8 = f2_mul_xi_n(f2_norm(f2_sub(f2_sub(f2_sqr_n(f2_add(x.c1.b2, x.c0.b1)), t4), t5)));
     t0 = f2_norm(f2_add(f2_mul_xi_n(t0), t1));

@@ -115,8 +115,8 @@ template <class X> GPBC_INLINE F6 f12p_mul_034(const X &x, const F6 &h, const F2
 // diagonal F2 products, the odd lane its three cross products.
 template <class X> GPBC_INLINE F6 f12p_mul(const X &x, const F6 &hx, const F6 &hy) {
     F6 t = f6_mul_t<false>(hx, hy);                          // even: t0 = a0 b0, odd: t1 = a1 b1
-    F6 sx = f6_norm(f6p_add_swap(x, hx, hx));               // own half + partner's half, swap fused into the addition
-    F6 sy = f6_norm(f6p_add_swap(x, hy, hy));
+    F6 sx = f6_norm(f6_add(hx, x.swap(hx)));                // (a DPP-fused addition here measured 3 % SLOWER: the 108 inline-asm
+    F6 sy = f6_norm(f6_add(hy, x.swap(hy)));                //  statements get in the scheduler's way; profiles/r02_microbench_pair.txt)
     // three F2 products per lane of sx * sy
     F2 xa = f2_sel(x.odd, f2_norm(f2_add(sx.b1, sx.b2)), sx.b0), ya = f2_sel(x.odd, f2_norm(f2_add(sy.b1, sy.b2)), sy.b0);
     F2 xb = f2_sel(x.odd, f2_norm(f2_add(sx.b0, sx.b1)), sx.b1), yb = f2_sel(x.odd, f2_norm(f2_add(sy.b0, sy.b1)), sy.b1);
@@ -128,11 +128,12 @@ template <class X> GPBC_INLINE F6 f12p_mul(const X &x, const F6 &hx, const F6 &h
     // one shared xi-multiplication: the odd lane needs xi (m12 - u1 - u2) for m, the even lane xi t1.b2 for v t1
     F2 xi1 = f2_mul_xi_nn(f2_sel(x.odd, f2_norm(f2_sub(f2_sub(cr.b0, dg.b1), dg.b2)), pt.b2));
     F2 m0 = f2_add(xi1, dg.b0);
-    F2 m1 = f2_add(f2_norm(f2_sub(f2_sub(cr.b1, dg.b0), dg.b1)), f2_mul_xi_nn(dg.b2));
+    F2 m1 = f2_add(f2_sub(f2_sub(cr.b1, dg.b0), dg.b1), f2_mul_xi_nn(dg.b2));
     F2 m2 = f2_add(f2_sub(f2_sub(cr.b2, dg.b0), dg.b2), dg.b1);
-    F6 m{m0, m1, f2_norm(m2)};                                // (a0+a1)(b0+b1): meaningful on the odd lane.  m0, m1 are sums of two
-                                                              // normalised values (limbs within [0, 2^30]) and enter the three-term
-                                                              // difference below un-normalised; m2 reaches -2^30 and would not fit
+    F6 m{m0, m1, m2};                                         // (a0+a1)(b0+b1): meaningful on the odd lane.  None of the three is
+                                                              // normalised: their limbs lie within [-2^30 + 2, 2^30 + 2^29] and the
+                                                              // three-term difference below stays inside int32 (lowest value exactly
+                                                              // -2^31; proved by the interval harness, tools/bounds_check.cpp)
     F6 even_out = f6_add(t, F6{xi1, pt.b0, pt.b1});           // t0 + v t1
     F6 odd_out = f6_sub(f6_sub(m, pt), t);                    // m - t0 - t1
     return f6_reduce(f6_norm(f6_sel(x.odd, odd_out, even_out)));

@@ -108,6 +108,29 @@ def test_lane_pair_forms_under_bounds(hc, oracle):
     assert (gt == ref).all()
 
 
+def test_multi_pairing_flows_under_bounds(hc, oracle):
+    """The two multi-pairing accumulators as the kernels run them: shared squarings over the scaled lines of a chunk
+    (k_miller_accumulate_chunks) and the fixed-Q form — raw line coefficients of every Q_i, evaluated at P_i by two
+    Fp x Fp2 products right before the sparse multiplication (k_q_lines + k_miller_accumulate_fixed_q).  Both must be
+    overflow-free for any input and give the oracle's product of pairings."""
+    n = 5
+    g1 = np.frombuffer(o.g1_to_bytes(o.G1_GEN), dtype=np.uint8)
+    g2 = np.frombuffer(o.g2_to_bytes(o.G2_GEN), dtype=np.uint8)
+    kp = np.frombuffer(b"".join(o.scalar_to_bytes(o.bench_scalar("P", 70 + i)) for i in range(n)), dtype=np.uint8).copy()
+    kq = np.frombuffer(b"".join(o.scalar_to_bytes(o.bench_scalar("Q", 70 + i)) for i in range(n)), dtype=np.uint8).copy()
+    P, Q = oracle.g1_scalar_mul(g1, kp), oracle.g2_scalar_mul(g2, kq)
+    want = oracle.multi_pair(P, Q, np.array([0, n], dtype=np.uint64))
+    f = np.zeros((1, 384), dtype=np.uint8)
+    hc.hc_pair_lanes_multi(vp(P), vp(Q), ctypes.c_size_t(n), vp(f))
+    assert (oracle.final_exp(f) == want).all()
+    f2 = np.zeros((1, 384), dtype=np.uint8)
+    hc.hc_pair_fixed_q(vp(P), vp(Q), ctypes.c_size_t(n), vp(f2), ctypes.c_int(0))
+    assert (oracle.final_exp(f2) == want).all()
+    gt = np.zeros((1, 384), dtype=np.uint8)
+    hc.hc_pair_fixed_q(vp(P), vp(Q), ctypes.c_size_t(n), vp(gt), ctypes.c_int(1))
+    assert (gt == want).all()
+
+
 def test_wnaf_digits_of_u():
     import re
     from conftest import ROOT

@@ -196,6 +196,33 @@ void hc_pair_lanes_multi(const uint8_t *P, const uint8_t *Q, size_t n, uint8_t *
     lane(false);
     t1.join();
 }
+// fixed-Q multi-pairing exactly as k_q_lines + k_miller_accumulate_fixed_q do it: the RAW line coefficients of every Q_i
+// (miller_lines_raw), evaluated at P_i inside the accumulator (two Fp x Fp2 products per line), shared squarings on one lane
+// pair; out = the Miller value of prod e(P_i, Q_i) before the final exponentiation (do_final_exp = 0) or the GT value
+void hc_pair_fixed_q(const uint8_t *P, const uint8_t *Q, size_t n, uint8_t *out, int do_final_exp) {
+    std::vector<LineE> raw(n * MILLER_LINES);
+    std::vector<G1A> pts(n);
+    for (size_t i = 0; i < n; i++) {
+        pts[i] = G1A{fe_load(P + 64 * i), fe_load(P + 64 * i + 32)};
+        G2A b{f2_load(Q + 128 * i), f2_load(Q + 128 * i + 64)};
+        int cnt = 0;
+        miller_lines_raw(b, [&](const LineE &l) { raw[i * MILLER_LINES + cnt++] = l; });
+    }
+    PairRendezvous rv;
+    auto lane = [&](bool odd) {
+        PairHost x{odd, &rv};
+        F6 h = miller_accumulate_multi(x, (int)n, [&](int p, int li) -> LineS {
+            const LineE &r = raw[(size_t)p * MILLER_LINES + li];
+            return LineS{f2_mul_fe(r.r0, pts[p].y), f2_mul_fe(r.r1, pts[p].x), r.r2};
+        });
+        if (do_final_exp) h = final_exp_pair(x, h);
+        f6_store(out + (odd ? 192 : 0), h);
+        stats_flush();
+    };
+    std::thread t1(lane, true);
+    lane(false);
+    t1.join();
+}
 void hc_gt_pair_ops(const uint8_t *A, const uint8_t *B, size_t n, uint8_t *mul, uint8_t *sqr, uint8_t *csqr, uint8_t *inv, uint8_t *frob1) {
     for (size_t i = 0; i < n; i++) {
         PairRendezvous rv;

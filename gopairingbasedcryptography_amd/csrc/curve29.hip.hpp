@@ -4,9 +4,9 @@
 // bibe/afp25_bibe/afp25_bibe_utils.go:48,51.  The affine result is canonical, so the algorithm is free
 // (gnark: GLV + Jacobian); here: Jacobian coordinates, a = 0 doubling, mixed addition, endomorphism splits (GLV for G1,
 // four-dimensional GLS for G2) with fixed joint windows over a common-Z table, safegcd inversion for the affine result.
-#ifndef GPBC_CURVE29_CUH
-#define GPBC_CURVE29_CUH
-#include "tower29.cuh"
+#ifndef GPBC_CURVE29_HIP_HPP
+#define GPBC_CURVE29_HIP_HPP
+#include "tower29.hip.hpp"
 
 namespace gpbc {
 

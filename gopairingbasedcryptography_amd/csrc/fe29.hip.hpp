@@ -12,8 +12,8 @@
 //
 // Static safety: compiled with -DGPBC_BOUNDS on the host (tools/bounds_check.cpp) every Fe carries data-independent
 // magnitude bounds and every multiplication asserts that its int64 columns cannot overflow.
-#ifndef GPBC_FE29_CUH
-#define GPBC_FE29_CUH
+#ifndef GPBC_FE29_HIP_HPP
+#define GPBC_FE29_HIP_HPP
 #include <stdint.h>
 #include <math.h>
 #if defined(__HIPCC__)
@@ -24,7 +24,7 @@
 #define GPBC_INLINE inline
 #define GPBC_NOINLINE
 #endif
-#include "bn254_constants29.cuh"
+#include "bn254_constants29.hip.hpp"
 
 #ifdef GPBC_BOUNDS
 #include <cassert>
@@ -667,6 +667,10 @@ GPBC_NOINLINE Fe fe_inv_fermat(const Fe &x) {
 }
 
 // ------------------------------------------------------------------------------------------------ inversion
+// Provenance: the inv30_* routines below restate, for nine 30-bit limbs and the BN254 modulus, the public constant-time
+// "modinv32" algorithm of libsecp256k1 (src/modinv32_impl.h, Pieter Wuille, after Bernstein-Yang "Fast constant-time gcd
+// computation and modular inversion" 2019 and Thomas Pornin's half-delta variant; MIT licence, Copyright (c) 2020 Peter
+// Dettman / Pieter Wuille).  Nothing here comes from the reference repository.
 // x^-1 (0 -> 0) by the Bernstein-Yang "safegcd" divsteps in the constant-time half-delta form (Pornin / Wuille:
 // zeta = -(delta + 1/2), 590 divsteps suffice below 2^256; here 20 batches of 30 = 600).  Every lane runs the same
 // straight-line code — no data-dependent branch — which is what a 64-lane wave needs; a batch is 30 divsteps on the low

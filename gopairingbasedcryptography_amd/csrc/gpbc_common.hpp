@@ -14,7 +14,7 @@
 #include <mutex>
 #include <vector>
 #include "../../include/gpbc_bn254.h"
-#include "curve29.cuh"
+#include "curve29.hip.hpp"
 
 using namespace gpbc;
 

@@ -73,7 +73,7 @@ GPBC_KERNEL k_g2_sum_level(const uint8_t *__restrict__ in, size_t n_in, uint8_t 
 }
 
 // ---- fixed-base tables (8-bit windows): entry ((b * 32 + w) * 255 + d - 1) = [d * 2^(8w)] base_b, affine, internal limb
-// form in the 128-byte-aligned row layout of curve29.cuh (tab_store / tab_load).  1 MB per G1 base, 2 MB per G2 base.
+// form in the 128-byte-aligned row layout of curve29.hip.hpp (tab_store / tab_load).  1 MB per G1 base, 2 MB per G2 base.
 constexpr int FB_WINDOWS = 32, FB_DIGITS = 255, FB_ENTRIES = FB_WINDOWS * FB_DIGITS;
 template <class F> __device__ __forceinline__ void fb_build_lane(const uint8_t *bases, size_t nbase, int32_t *table, uint8_t *base_inf, int32_t *tabws, size_t first, size_t count) {
     size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;

@@ -1,8 +1,8 @@
 // libgpbc_bn254.so, unit 2 of 4: Miller loop (two phases, single pairs / shared-squaring chunks / fixed Q), final
 // exponentiation, segment products and the GT kernels, with their C-ABI entries (include/gpbc_bn254.h).  gfx950 only.
 #include "gpbc_common.hpp"
-#include "pairing29.cuh"
-#include "pairing29_pair.cuh"
+#include "pairing29.hip.hpp"
+#include "pairing29_pair.hip.hpp"
 
 static_assert(LINE_BYTES_PER_PAIR == (size_t)MILLER_LINES * LINE_WORDS * sizeof(int32_t), "lines workspace row size");
 
@@ -41,7 +41,7 @@ GPBC_KERNEL k_miller_lines(const uint8_t *__restrict__ P, const uint8_t *__restr
 }
 
 // Phase B and the final exponentiation run with one pairing per LANE PAIR (even lane: C0, odd lane: C1 of every Fp12
-// value, halves swapped by DPP — tower29_pair.cuh), so a batch of n pairings is a grid of 2n lanes.
+// value, halves swapped by DPP — tower29_pair.hip.hpp), so a batch of n pairings is a grid of 2n lanes.
 GPBC_KERNEL k_miller_accumulate(const uint8_t *__restrict__ P, const uint8_t *__restrict__ Q, const int32_t *__restrict__ lines,
                                 uint8_t *__restrict__ f_out, size_t n, size_t stride) {
     size_t lane = (size_t)blockIdx.x * BLOCK + threadIdx.x;

@@ -1,10 +1,10 @@
-// libgpbc_bn254.so, unit 4 of 4: gnark wire formats (csrc/wire29.cuh) and the group part of hash to curve
-// (csrc/h2c29.cuh), with their C-ABI entries (include/gpbc_bn254.h).  gfx950 only.
+// libgpbc_bn254.so, unit 4 of 4: gnark wire formats (csrc/wire29.hip.hpp) and the group part of hash to curve
+// (csrc/h2c29.hip.hpp), with their C-ABI entries (include/gpbc_bn254.h).  gfx950 only.
 #include "gpbc_common.hpp"
-#include "wire29.cuh"
-#include "h2c29.cuh"
+#include "wire29.hip.hpp"
+#include "h2c29.hip.hpp"
 
-// ---- wire formats (csrc/wire29.cuh): one element per lane
+// ---- wire formats (csrc/wire29.hip.hpp): one element per lane
 GPBC_KERNEL k_g1_encode(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, size_t n, int compressed) {
     size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -36,7 +36,7 @@ GPBC_KERNEL k_gt_decode(const uint8_t *__restrict__ in, uint8_t *__restrict__ ou
     ok[i] = gt_wire_decode(out + i * GPBC_GT_BYTES, in + i * GPBC_GT_BYTES) ? 1 : 0;
 }
 
-// ---- hash to curve, group part (csrc/h2c29.cuh): u = n x 2 field elements -> n points
+// ---- hash to curve, group part (csrc/h2c29.hip.hpp): u = n x 2 field elements -> n points
 GPBC_KERNEL k_g1_map_fields(const uint8_t *__restrict__ u, uint8_t *__restrict__ out, size_t n) {
     size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;

@@ -6,9 +6,9 @@
 // Appendix H.1 find_z_svdw accepts; tools/gen_constants.py derives it and c1..c4).  clear_cofactor is Fuentes-Castaneda et al. §6.1 as
 // gnark's G2Jac.ClearCofactor does it:  [x]P + psi([3x]P) + psi^2([x]P) + psi^3(P),  x = the curve parameter u.
 // The message hashing itself (expand_message_xmd with SHA-256, L = 48) is sequential byte work and stays on the host.
-#ifndef GPBC_H2C29_CUH
-#define GPBC_H2C29_CUH
-#include "wire29.cuh"
+#ifndef GPBC_H2C29_HIP_HPP
+#define GPBC_H2C29_HIP_HPP
+#include "wire29.hip.hpp"
 
 namespace gpbc {
 
@@ -74,7 +74,7 @@ template <class F> GPBC_NOINLINE void map_to_curve_svdw(AffP<F> &out, const F &u
     out.x = x; out.y = y; out.inf = false;
 }
 
-// psi^j on Jacobian coordinates of the twist: jac_psi_tw (wire29.cuh)
+// psi^j on Jacobian coordinates of the twist: jac_psi_tw (wire29.hip.hpp)
 GPBC_INLINE JacP<F2> jac_psi(const JacP<F2> &p, int j) { return jac_psi_tw(p, j); }
 // [x]P + psi([3x]P) + psi^2([x]P) + psi^3(P) for an affine twist point P
 GPBC_NOINLINE void g2_clear_cofactor29(JacP<F2> &out, const AffP<F2> &p) {

@@ -4,10 +4,10 @@
 // bibe/afp25_bibe/afp25_bibe.go:227,395,399,403, signature/bls01_signature/bls_signature.go:81.
 // The GT value is the unique residue e(P,Q)^s (s = 2u(6u^2+3u+1)), so any correct
 // evaluation order gives gnark's bytes once the result is made canonical.
-#ifndef GPBC_PAIRING29_CUH
-#define GPBC_PAIRING29_CUH
-#include "bn254_constants.cuh"
-#include "tower29.cuh"
+#ifndef GPBC_PAIRING29_HIP_HPP
+#define GPBC_PAIRING29_HIP_HPP
+#include "bn254_constants.hip.hpp"
+#include "tower29.hip.hpp"
 
 namespace gpbc {
 
@@ -29,17 +29,17 @@ GPBC_INLINE void g2_double_step(G2P &t, LineE &l) {
     F2 H = f2_sub(f2_sqr_n(f2_add(t.y, t.z)), f2_add(B, C));
     F2 J = f2_sqr(t.x);
     F2 EE = f2_sqr(E);
-    t.x = f2_mul(f2_norm(A), f2_norm(f2_sub(B, F)));
+    t.x = f2_mul(A, f2_norm(f2_sub(B, F)));
     t.y = f2_norm(f2_sub(f2_sqr_n(G), f2_add(f2_dbl(EE), EE)));
     t.z = f2_mul(B, f2_norm(H));
-    l.r0 = f2_norm(f2_neg(H));
+    l.r0 = f2_neg(H);                        // (-2^29, 2^30): a line coefficient only enters products with normalised partners
     l.r1 = f2_norm(f2_add(f2_dbl(J), J));
-    l.r2 = f2_norm(f2_sub(E, B));
+    l.r2 = f2_sub(E, B);
 }
 // Chord through T and affine Q, T <- T + Q
 GPBC_INLINE void g2_add_step(G2P &t, LineE &l, const G2A &q) {
-    F2 O = f2_norm(f2_sub(t.y, f2_mul(q.y, t.z)));
-    F2 L = f2_norm(f2_sub(t.x, f2_mul(q.x, t.z)));
+    F2 O = f2_sub(t.y, f2_mul(q.y, t.z));     // differences of two normalised values (limbs within +-2^29) go into the
+    F2 L = f2_sub(t.x, f2_mul(q.x, t.z));     // products as they are: signed columns stay below 27 * 2^58 (interval harness)
     F2 C = f2_sqr(O);
     F2 D = f2_sqr(L);
     F2 E = f2_mul(L, D);
@@ -48,11 +48,11 @@ GPBC_INLINE void g2_add_step(G2P &t, LineE &l, const G2A &q) {
     F2 H = f2_norm(f2_sub(f2_add(E, F), f2_dbl(G)));
     F2 t1 = f2_mul(t.y, E);
     t.x = f2_mul(L, H);
-    t.y = f2_norm(f2_sub(f2_mul(f2_norm(f2_sub(G, H)), O), t1));
+    t.y = f2_norm(f2_sub(f2_mul(f2_sub(G, H), O), t1));
     t.z = f2_mul(E, t.z);
     l.r0 = L;
     l.r1 = f2_neg(O);
-    l.r2 = f2_norm(f2_sub(f2_mul(q.x, O), f2_mul(L, q.y)));
+    l.r2 = f2_sub(f2_mul(q.x, O), f2_mul(L, q.y));
 }
 // A Miller step's line already evaluated at P: l = c0 + c3 w + c4 v w with c0 = r0*yP, c3 = r1*xP, c4 = r2
 struct LineS { F2 c0, c3, c4; };
@@ -133,7 +133,7 @@ template <class Src> GPBC_INLINE F12 miller_accumulate(Src &&next) {
 }
 
 // Both phases in one call on one lane.  The kernels do not use this form (phase B and the final exponentiation run on
-// lane pairs, pairing29_pair.cuh); it is the single-lane statement of the same mathematics that tools/bounds_check.cpp
+// lane pairs, pairing29_pair.hip.hpp); it is the single-lane statement of the same mathematics that tools/bounds_check.cpp
 // runs under bound instrumentation and compares with the oracle.
 GPBC_INLINE F12 miller_loop29(const G1A &p, const G2A &q) {
     LineS lines[MILLER_LINES];

@@ -1,10 +1,10 @@
-// Miller accumulator and final exponentiation with one Fp12 value per LANE PAIR (tower29_pair.cuh): even lane = C0,
-// odd lane = C1.  Same mathematics and operation order as pairing29.cuh (which remains the single-lane form used by
-// the line phase, the GT kernels and the host harness); see tower29_pair.cuh for why the state is split.
-#ifndef GPBC_PAIRING29_PAIR_CUH
-#define GPBC_PAIRING29_PAIR_CUH
-#include "pairing29.cuh"
-#include "tower29_pair.cuh"
+// Miller accumulator and final exponentiation with one Fp12 value per LANE PAIR (tower29_pair.hip.hpp): even lane = C0,
+// odd lane = C1.  Same mathematics and operation order as pairing29.hip.hpp (which remains the single-lane form used by
+// the line phase, the GT kernels and the host harness); see tower29_pair.hip.hpp for why the state is split.
+#ifndef GPBC_PAIRING29_PAIR_HIP_HPP
+#define GPBC_PAIRING29_PAIR_HIP_HPP
+#include "pairing29.hip.hpp"
+#include "tower29_pair.hip.hpp"
 
 namespace gpbc {
 

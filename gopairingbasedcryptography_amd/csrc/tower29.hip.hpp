@@ -1,12 +1,12 @@
-// Extension tower over the 29-bit-limb field (fe29.cuh); gnark E2/E6/E12 structure:
+// Extension tower over the 29-bit-limb field (fe29.hip.hpp); gnark E2/E6/E12 structure:
 //   F2 = Fp[i]/(i^2+1) {a0,a1};  F6 = F2[v]/(v^3-(9+i)) {b0,b1,b2};  F12 = F6[w]/(w^2-v) {c0,c1}
 // Convention: every tower function takes operands whose limbs are "N-class" (|limb| <= 2^29 + small) and returns
 // N-class results; sums and differences in between run carry-free and are re-normalised (fe_norm) only where a
 // product needs it.  F2 products are lazy: two wide column accumulations + two reductions (4 x 81 + 2 x 81 MADs)
 // instead of Karatsuba's three full multiplications — MADs cost the same as adds on this machine.
-#ifndef GPBC_TOWER29_CUH
-#define GPBC_TOWER29_CUH
-#include "fe29.cuh"
+#ifndef GPBC_TOWER29_HIP_HPP
+#define GPBC_TOWER29_HIP_HPP
+#include "fe29.hip.hpp"
 
 namespace gpbc {
 

@@ -13,9 +13,9 @@
 //
 // X is the exchange policy: X::odd (lane parity) and X::swap(F2/F6) -> the partner lane's value.  The device policy
 // uses DPP; tools/bounds_check.cpp runs the two lanes as two host threads with a rendezvous.
-#ifndef GPBC_TOWER29_PAIR_CUH
-#define GPBC_TOWER29_PAIR_CUH
-#include "tower29.cuh"
+#ifndef GPBC_TOWER29_PAIR_HIP_HPP
+#define GPBC_TOWER29_PAIR_HIP_HPP
+#include "tower29.hip.hpp"
 
 namespace gpbc {
 
@@ -108,7 +108,7 @@ template <class X> GPBC_INLINE F6 f12p_mul_034(const X &x, const F6 &h, const F2
     F6 p1 = x.swap(r1);
     F6 add = f6_sel(x.odd, p1, f6_mul_v_t<false>(p1));
     return f6_reduce_arith(f6_norm(f6_add(r0, add)));                    // the one value reduction of this step (no table loads
-                                                                         // here: this runs beside the lines stream, see fe29.cuh)
+                                                                         // here: this runs beside the lines stream, see fe29.hip.hpp)
 }
 
 // full product (Karatsuba over F6).  The third product (a0+a1)(b0+b1) is itself split: the even lane computes its three

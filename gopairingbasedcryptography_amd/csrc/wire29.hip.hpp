@@ -8,9 +8,9 @@
 // G1Affine.Bytes / GT.Bytes (ibe/gentry06_ibe/gentry06_ibe.go:322-324, hash/hash_from_gt.go:5-8).
 // Decoding follows SetBytes: canonical-range check of every coordinate, square root for the compressed forms (error
 // if none), curve / subgroup check (G1: on the curve, cofactor 1; G2: on the twist and in the order-r subgroup).
-#ifndef GPBC_WIRE29_CUH
-#define GPBC_WIRE29_CUH
-#include "curve29.cuh"
+#ifndef GPBC_WIRE29_HIP_HPP
+#define GPBC_WIRE29_HIP_HPP
+#include "curve29.hip.hpp"
 
 namespace gpbc {
 

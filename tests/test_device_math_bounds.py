@@ -1,4 +1,4 @@
-"""CPU verification of the DEVICE arithmetic: csrc/fe29.cuh .. pairing29.cuh compiled for the host with
+"""CPU verification of the DEVICE arithmetic: csrc/fe29.hip.hpp .. pairing29.hip.hpp compiled for the host with
 -DGPBC_BOUNDS (tools/bounds_check.cpp).  In that build every field element carries data-independent magnitude
 bounds and every Montgomery product aborts if its int64 column accumulators could overflow for ANY input, so a
 run that finishes is a proof of overflow-freedom for the straight-line code paths it exercised; the values it
@@ -21,7 +21,7 @@ SO = os.path.join(ROOT, "tools", "libgpbc_bounds.so")
 def hc():
     src = os.path.join(ROOT, "tools", "bounds_check.cpp")
     hdrs = [os.path.join(ROOT, "gopairingbasedcryptography_amd", "csrc", f)
-            for f in ("fe29.cuh", "tower29.cuh", "tower29_pair.cuh", "curve29.cuh", "pairing29.cuh", "pairing29_pair.cuh", "wire29.cuh")]
+            for f in ("fe29.hip.hpp", "tower29.hip.hpp", "tower29_pair.hip.hpp", "curve29.hip.hpp", "pairing29.hip.hpp", "pairing29_pair.hip.hpp", "wire29.hip.hpp")]
     if not os.path.exists(SO) or any(os.path.getmtime(f) > os.path.getmtime(SO) for f in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-pthread", "-std=c++17", "-DGPBC_BOUNDS", "-shared", "-fPIC", "-o", SO, src])
     return ctypes.CDLL(SO)
@@ -83,7 +83,7 @@ def test_bound_margins(hc):
 
 
 def test_lane_pair_forms_under_bounds(hc, oracle):
-    """tower29_pair.cuh / pairing29_pair.cuh: one Fp12 value per lane pair (two host threads + rendezvous stand in for
+    """tower29_pair.hip.hpp / pairing29_pair.hip.hpp: one Fp12 value per lane pair (two host threads + rendezvous stand in for
     the DPP swap).  Every pair-form operation and the full pair-form pairing must match the oracle bit for bit."""
     n = 3
     g1 = np.frombuffer(o.g1_to_bytes(o.G1_GEN), dtype=np.uint8)
@@ -134,13 +134,13 @@ def test_multi_pairing_flows_under_bounds(hc, oracle):
 def test_wnaf_digits_of_u():
     import re
     from conftest import ROOT
-    text = open(os.path.join(ROOT, "gopairingbasedcryptography_amd", "csrc", "bn254_constants.cuh")).read()
+    text = open(os.path.join(ROOT, "gopairingbasedcryptography_amd", "csrc", "bn254_constants.hip.hpp")).read()
     digits = [int(x) for x in re.search(r"#define GPBC_U_WNAF4 \{([^}]*)\}", text).group(1).split(",")]
     assert sum(d << i for i, d in enumerate(digits)) == o.U and all(d == 0 or (d % 2 and abs(d) < 8) for d in digits)
 
 
 def test_glv_split_identity(hc):
-    """k == k1 + k2*lambda (mod r) with |k1|,|k2| < 2^130 for edge and random 256-bit scalars (curve29.cuh glv_split)."""
+    """k == k1 + k2*lambda (mod r) with |k1|,|k2| < 2^130 for edge and random 256-bit scalars (curve29.hip.hpp glv_split)."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import gen_constants as gc

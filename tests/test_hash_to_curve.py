@@ -1,6 +1,6 @@
 """Hash to curve on the CPU: RFC 9380's published expand_message_xmd vectors, the oracle against the
 committed fixture, the host-side hashing of the product mirror (hash_to.py — plain hashlib, no GPU needed) against the
-oracle, and the DEVICE code of csrc/h2c29.cuh compiled for the host under the bounds harness against the fixture."""
+oracle, and the DEVICE code of csrc/h2c29.hip.hpp compiled for the host under the bounds harness against the fixture."""
 import ctypes
 import os
 import subprocess
@@ -18,7 +18,7 @@ SO = os.path.join(ROOT, "tools", "libgpbc_bounds.so")
 def hc():
     src = os.path.join(ROOT, "tools", "bounds_check.cpp")
     hdrs = [os.path.join(ROOT, "gopairingbasedcryptography_amd", "csrc", f)
-            for f in ("fe29.cuh", "tower29.cuh", "curve29.cuh", "wire29.cuh", "h2c29.cuh")]
+            for f in ("fe29.hip.hpp", "tower29.hip.hpp", "curve29.hip.hpp", "wire29.hip.hpp", "h2c29.hip.hpp")]
     if not os.path.exists(SO) or any(os.path.getmtime(f) > os.path.getmtime(SO) for f in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-pthread", "-std=c++17", "-DGPBC_BOUNDS", "-shared", "-fPIC", "-o", SO, src])
     return ctypes.CDLL(SO)

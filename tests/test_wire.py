@@ -1,5 +1,5 @@
 """Wire formats on the CPU: the big-integer oracle against the committed fixture, structural facts of
-the published gnark encoding, and the DEVICE code of csrc/wire29.cuh compiled for the host under the bounds harness
+the published gnark encoding, and the DEVICE code of csrc/wire29.hip.hpp compiled for the host under the bounds harness
 (tools/bounds_check.cpp) against the same fixture.  The GPU parity tests are in test_gpu_parity.py."""
 import ctypes
 import os
@@ -18,7 +18,7 @@ SO = os.path.join(ROOT, "tools", "libgpbc_bounds.so")
 def hc():
     src = os.path.join(ROOT, "tools", "bounds_check.cpp")
     hdrs = [os.path.join(ROOT, "gopairingbasedcryptography_amd", "csrc", f)
-            for f in ("fe29.cuh", "tower29.cuh", "tower29_pair.cuh", "curve29.cuh", "pairing29.cuh", "pairing29_pair.cuh", "wire29.cuh")]
+            for f in ("fe29.hip.hpp", "tower29.hip.hpp", "tower29_pair.hip.hpp", "curve29.hip.hpp", "pairing29.hip.hpp", "pairing29_pair.hip.hpp", "wire29.hip.hpp")]
     if not os.path.exists(SO) or any(os.path.getmtime(f) > os.path.getmtime(SO) for f in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-pthread", "-std=c++17", "-DGPBC_BOUNDS", "-shared", "-fPIC", "-o", SO, src])
     return ctypes.CDLL(SO)

@@ -1,4 +1,4 @@
-// Host build of the DEVICE arithmetic (csrc/fe29.cuh, tower29.cuh, curve29.cuh, pairing29.cuh) with -DGPBC_BOUNDS:
+// Host build of the DEVICE arithmetic (csrc/fe29.hip.hpp, tower29.hip.hpp, curve29.hip.hpp, pairing29.hip.hpp) with -DGPBC_BOUNDS:
 // every field element carries data-independent magnitude bounds and every product asserts that its int64 column
 // accumulators cannot overflow (abort() on violation).  This is a verification harness for tests/ only — it is
 // never loaded by the product path (which has no CPU fallback).
@@ -8,11 +8,11 @@
 #define GPBC_BOUNDS
 #endif
 #include <cstring>
-#include "../gopairingbasedcryptography_amd/csrc/curve29.cuh"
-#include "../gopairingbasedcryptography_amd/csrc/pairing29.cuh"
-#include "../gopairingbasedcryptography_amd/csrc/pairing29_pair.cuh"
-#include "../gopairingbasedcryptography_amd/csrc/wire29.cuh"
-#include "../gopairingbasedcryptography_amd/csrc/h2c29.cuh"
+#include "../gopairingbasedcryptography_amd/csrc/curve29.hip.hpp"
+#include "../gopairingbasedcryptography_amd/csrc/pairing29.hip.hpp"
+#include "../gopairingbasedcryptography_amd/csrc/pairing29_pair.hip.hpp"
+#include "../gopairingbasedcryptography_amd/csrc/wire29.hip.hpp"
+#include "../gopairingbasedcryptography_amd/csrc/h2c29.hip.hpp"
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -259,7 +259,7 @@ void hc_gt_exp_pair(const uint8_t *A, const uint8_t *K, size_t n, uint8_t *out) 
         t1.join();
     }
 }
-// wire formats (csrc/wire29.cuh): kind 0 G1, 1 G2, 2 GT; the same per-element functions the kernels call
+// wire formats (csrc/wire29.hip.hpp): kind 0 G1, 1 G2, 2 GT; the same per-element functions the kernels call
 void hc_wire_encode(int kind, const uint8_t *in, size_t n, int compressed, uint8_t *out) {
     for (size_t i = 0; i < n; i++) {
         if (kind == 0) g1_wire_encode(out + i * (compressed ? 32 : 64), in + 64 * i, compressed != 0);
@@ -274,7 +274,7 @@ void hc_wire_decode(int kind, const uint8_t *in, int elem_bytes, size_t n, uint8
         else ok[i] = gt_wire_decode(out + 384 * i, in + 384 * i);
     }
 }
-// hash to curve, group part (csrc/h2c29.cuh): U = n x 2 field elements (gnark fp.Element / E2), out = n affine points
+// hash to curve, group part (csrc/h2c29.hip.hpp): U = n x 2 field elements (gnark fp.Element / E2), out = n affine points
 void hc_map_fields(int g2, const uint8_t *U, size_t n, uint8_t *out) {
     for (size_t i = 0; i < n; i++) {
         if (!g2) {

@@ -1,9 +1,9 @@
-// Micro-benchmark of the field-layer leaves (csrc/fe29.cuh) on gfx950: cycles per fe_mul / fe_mul2 / fe_norm /
+// Micro-benchmark of the field-layer leaves (csrc/fe29.hip.hpp) on gfx950: cycles per fe_mul / fe_mul2 / fe_norm /
 // fe_reduce call at 1, 2 and 4 waves per SIMD.  build: hipcc -O3 --offload-arch=gfx950 -std=c++17 tools/microbench_fe.hip -o tools/microbench_fe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
-#include "../gopairingbasedcryptography_amd/csrc/tower29.cuh"
+#include "../gopairingbasedcryptography_amd/csrc/tower29.hip.hpp"
 using namespace gpbc;
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 

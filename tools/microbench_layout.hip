@@ -4,7 +4,7 @@
 // Built:      one field element per LANE (nine signed 29-bit limbs in nine registers), one Fp12 value per lane pair.
 //
 // This program measures the core of the question — a lazy Fp2 product (the leaf every tower operation is made of):
-//   per-lane      f2_mul_leaf of csrc/tower29.cuh: 64 products per wave-call, 486 v_mad_i64_i32 + 127 other VALU instructions
+//   per-lane      f2_mul_leaf of csrc/tower29.hip.hpp: 64 products per wave-call, 486 v_mad_i64_i32 + 127 other VALU instructions
 //   cooperative   the same product with the LIMBS SPREAD OVER NINE LANES (seven products per wave, lane 63 idle): lane j holds
 //                 limb j of a0, a1, b0, b1; operand limbs travel by ds_bpermute_b32 (the LDS crossbar, the "wavefront shuffle"
 //                 of gfx950 for arbitrary lane patterns), column sums live one per lane, the Montgomery reduction walks the
@@ -17,7 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include "../gopairingbasedcryptography_amd/csrc/tower29.cuh"
+#include "../gopairingbasedcryptography_amd/csrc/tower29.hip.hpp"
 using namespace gpbc;
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 

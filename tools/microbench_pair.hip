@@ -1,11 +1,11 @@
-// Micro-benchmark of the lane-pair Fp12 primitives (csrc/tower29_pair.cuh) on gfx950: SIMD cycles per wave-call of
+// Micro-benchmark of the lane-pair Fp12 primitives (csrc/tower29_pair.hip.hpp) on gfx950: SIMD cycles per wave-call of
 // f12p_cyclo_sqr / f12p_mul / f12p_sqr / f12p_mul_034 and of the F2 leaves at 2 waves per SIMD, beside the cycles their
 // MAD instructions alone would take (4.5 cycles per wave-instruction, profiles/r01_microbench_valu.txt).
 // build: hipcc -O3 --offload-arch=gfx950 -std=c++17 tools/microbench_pair.hip -o tools/microbench_pair
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
-#include "../gopairingbasedcryptography_amd/csrc/tower29_pair.cuh"
+#include "../gopairingbasedcryptography_amd/csrc/tower29_pair.hip.hpp"
 using namespace gpbc;
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
@@ -27,7 +27,7 @@ __global__ void __launch_bounds__(64, 2) bench(const uint8_t *in, uint8_t *out, 
         else if (OP == 5) { h.b0 = f2_sqr(h.b0); h.b1 = f2_sqr(h.b1); h.b2 = f2_sqr(h.b2); }
         else if (OP == 6) { h = f6_reduce(f6_norm(f6_add(h, g))); }
         else if (OP == 7) { h = f6_norm(f6_add(h, x.swap(h))); }
-        // single-lane forms (tower29.cuh): one whole Fp12 value per lane, 64 values per wave-call instead of 32
+        // single-lane forms (tower29.hip.hpp): one whole Fp12 value per lane, 64 values per wave-call instead of 32
         else if (OP == 8) { F12 z = f12_cyclo_sqr(F12{h, g}); h = z.c0; g = z.c1; }
         else if (OP == 9) { F12 z = f12_mul(F12{h, g}, F12{g, h}); h = z.c0; g = z.c1; }
         else if (OP == 10) { F12 z = f12_sqr(F12{h, g}); h = f6_reduce(z.c0); g = f6_reduce(z.c1); }

@@ -51,7 +51,7 @@ template <class F> GPBC_INLINE void jac_dbl(JacP<F> &r, const JacP<F> &p) {
     F E = g_norm(g_add(g_dbl(A), A));
     F FF = g_sqr(E);
     F x3 = g_norm(g_sub(FF, g_dbl(S)));
-    F y3 = g_norm(g_sub(g_mul(E, g_norm(g_sub(S, x3))), C8));
+    F y3 = g_sub(g_mul(E, g_sub(S, x3)), C8);             // differences of normalised values stay within +-2^29: no normalisation (interval harness)
     F z3 = g_mul(p.y, g_norm(g_dbl(p.z)));
     r.x = x3; r.y = y3; r.z = z3; r.inf = false;
 }
@@ -62,7 +62,7 @@ template <class F> GPBC_INLINE void jac_add_mixed(JacP<F> &r, const JacP<F> &p, 
     F Z1Z1 = g_sqr(p.z);
     F U2 = g_mul(q.x, Z1Z1);
     F S2 = g_mul(g_mul(q.y, p.z), Z1Z1);
-    F H = g_norm(g_sub(U2, p.x));
+    F H = g_sub(U2, p.x);
     F rr = g_norm(g_sub(S2, p.y));
     if (g_is_zero(H)) {
         if (g_is_zero(rr)) { jac_dbl(r, p); return; }
@@ -75,7 +75,7 @@ template <class F> GPBC_INLINE void jac_add_mixed(JacP<F> &r, const JacP<F> &p, 
     F J = g_mul(H, I);
     F V = g_mul(p.x, I);
     F x3 = g_norm(g_sub(g_sub(g_sqr(rr), J), g_dbl(V)));
-    F y3 = g_norm(g_sub(g_mul(rr, g_norm(g_sub(V, x3))), g_dbl(g_mul(p.y, J))));
+    F y3 = g_norm(g_sub(g_mul(rr, g_sub(V, x3)), g_dbl(g_mul(p.y, J))));
     F z3 = g_norm(g_sub(g_sub(g_sqr(g_norm(g_add(p.z, H))), Z1Z1), HH));
     r.x = x3; r.y = y3; r.z = z3; r.inf = false;
 }
@@ -86,8 +86,8 @@ template <class F> GPBC_INLINE void jac_add(JacP<F> &r, const JacP<F> &p, const 
     F Z1Z1 = g_sqr(p.z), Z2Z2 = g_sqr(q.z);
     F U1 = g_mul(p.x, Z2Z2), U2 = g_mul(q.x, Z1Z1);
     F S1 = g_mul(g_mul(p.y, q.z), Z2Z2), S2 = g_mul(g_mul(q.y, p.z), Z1Z1);
-    F H = g_norm(g_sub(U2, U1));
-    F rr = g_norm(g_sub(S2, S1));
+    F H = g_sub(U2, U1);
+    F rr = g_sub(S2, S1);
     if (g_is_zero(H)) {
         if (g_is_zero(rr)) { jac_dbl(r, p); return; }
         jac_set_inf(r);
@@ -99,7 +99,7 @@ template <class F> GPBC_INLINE void jac_add(JacP<F> &r, const JacP<F> &p, const 
     F J = g_mul(H, I);
     F V = g_mul(U1, I);
     F x3 = g_norm(g_sub(g_sub(g_sqr(rr), J), g_dbl(V)));
-    F y3 = g_norm(g_sub(g_mul(rr, g_norm(g_sub(V, x3))), g_dbl(g_mul(S1, J))));
+    F y3 = g_norm(g_sub(g_mul(rr, g_sub(V, x3)), g_dbl(g_mul(S1, J))));
     F z3 = g_mul(g_norm(g_sub(g_sub(g_sqr(g_norm(g_add(p.z, q.z))), Z1Z1), Z2Z2)), H);
     r.x = x3; r.y = y3; r.z = z3; r.inf = false;
 }

@@ -4,7 +4,8 @@ range with NO data-path collective; a collective appears only w
 
   * aggregate_verify  (BASELINE config 3): each rank reduces its shard to partial sums A_g in G1 (64 B) and B_g in G2
     (128 B), one all-gather of 192 B per rank, then every rank adds the partials and runs the 2-pairing check;
-  * pair_batch_gather (BASELINE config 5): all-gather of the per-shard GT values (n/G x 384 B per rank).
+  * pair_batch_gather / afp25_decrypt_gather (BASELINE config 5): all-gather of the per-shard GT values (n/G x 384 B per
+    rank) — plain pairings, or the AFP25 batch decryption (3-pair multi-pairing + GT.Div per item) whose masks the config names.
 
 `engine` is the compute backend: the `bn254` module of this package on a GPU box.  The CPU tests pass an
 oracle-backed stand-in with the same function names — this module itself never imports the oracle.
@@ -72,6 +73,16 @@ def pair_batch_gather(engine, P_local, Q_local, n_total, device=None):
     """Config 5 shape: every rank pairs its own shard, then all ranks receive all n_total GT values."""
     gt = engine.pair_batch(P_local, Q_local)
     return all_gather_rows(gt, n_total, device=device, engine=engine)
+
+
+def afp25_decrypt_gather(engine, D_local, pi_local, sk_local, C1_local, C2_local, n_total, device=None):
+    """BASELINE config 5 end to end: every rank decrypts its shard of the (ciphertext, identity) items —
+    m_i = C2_i / (e(D_i, C1_i[0]) e(pi_i, C1_i[1]) e(sk_i, C1_i[2])), bibe/afp25_bibe/afp25_bibe.go:395-413, through
+    afp25.decrypt_batch_arrays: one 3-pair multi-pairing and one GT.Div per item — and all ranks receive all n_total GT
+    values by ONE all-gather (the library's RCCL communicator on the GPU box, gloo in the CPU tests)."""
+    from . import afp25
+    out = afp25.decrypt_batch_arrays(engine, D_local, pi_local, sk_local, C1_local, C2_local)
+    return all_gather_rows(out, n_total, device=device, engine=engine)
 
 
 def aggregate_verify(engine, pk_local, rho_local, sigma_local, H, g1, neg, device=None):

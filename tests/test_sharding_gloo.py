@@ -31,10 +31,20 @@ class OracleEngine:
         self.o = oracle_lib
 
     def pair_batch(self, P, Q): return self.o.pair_batch(P, Q)
-    def g1_scalar_mul(self, b, k): return self.o.g1_scalar_mul(b, k)
-    def g2_scalar_mul(self, b, k): return self.o.g2_scalar_mul(b, k)
+    def g1_scalar_mul(self, b, k): return self.o.g1_scalar_mul(b, self._k(k))
+    def g2_scalar_mul(self, b, k): return self.o.g2_scalar_mul(b, self._k(k))
     def g1_sum(self, p): return self.o.g1_sum(p)
     def g2_sum(self, p): return self.o.g2_sum(p)
+
+    def multi_pair(self, P, Q, off): return self.o.multi_pair(P, Q, off)
+    def gt_mul(self, a, b): return self.o.gt_mul(a, b)
+    def gt_div(self, a, b): return self.o.gt_div(a, b)
+
+    def _k(self, ks):
+        import bn254_py as o
+        return np.frombuffer(b"".join(o.scalar_to_bytes(int(k) % o.R) for k in ks), dtype=np.uint8) if isinstance(ks, (list, tuple)) else ks
+
+    def gt_exp(self, x, k): return self.o.gt_exp(x, self._k(k))
 
     def pairing_check(self, P, Q):
         import bn254_py as o
@@ -71,7 +81,19 @@ def _worker(rank, world, port, n, q):
     if rank == world - 1:
         sig = sig.copy(); sig[0] = eng.g2_scalar_mul(H, sc("forged", 0, 1))[0]
     ok_forged = sharding.aggregate_verify(eng, pk, rho, sig, H, g1, neg)
-    q.put((rank, ok_gather, ok_valid, ok_forged))
+    # --- config 5 end to end: AFP25 batch decryption of the rank's shard of items, then the all-gather of the GT masks
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from afp25_fixture import Instance
+    from gopairingbasedcryptography_amd import afp25
+    inst = Instance(eng, B=4, n_items=3)                         # same instance on every rank (deterministic), 3 items: shards 2 + 1
+    pis = [afp25.commit_g1(eng, inst.g1, inst.tau_powers, afp25.quotient_by_root(inst.f, it[0])) for it in inst.items]
+    a, b = sharding.shard_range(len(inst.items), rank, world)
+    sel = list(range(a, b))
+    got = sharding.afp25_decrypt_gather(eng, np.stack([np.asarray(inst.D)] * len(sel)), np.stack([pis[i] for i in sel]),
+                                        np.stack([np.asarray(inst.sk)] * len(sel)), np.stack([inst.items[i][1] for i in sel]),
+                                        np.stack([inst.items[i][2] for i in sel]), len(inst.items)).numpy()
+    ok_afp25 = bool((got == np.stack(inst.msgs)).all())
+    q.put((rank, ok_gather, ok_valid, ok_forged, ok_afp25))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -88,7 +110,8 @@ def test_world2_gather_and_aggregate_verify():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, ok_gather, ok_valid, ok_forged in res:
+    for rank, ok_gather, ok_valid, ok_forged, ok_afp25 in res:
         assert ok_gather, rank
         assert ok_valid is True, rank
         assert ok_forged is False, rank
+        assert ok_afp25, rank

@@ -212,8 +212,11 @@ def multi_pair(P, Q, seg_off, out=None, workspace=None):
         if seg_off.dtype not in (torch.int64, torch.uint64) or not seg_off.is_cuda or not seg_off.is_contiguous() or seg_off.device != P.device:
             raise ValueError("a device segment table must be a contiguous int64 / uint64 CUDA tensor on the points' device")
         k = seg_off.numel() - 1
-        if k < 1 or int(seg_off[0].item()) != 0 or int(seg_off[-1].item()) != n:
-            raise ValueError("invalid inputs sizes")          # the segment table must cover exactly the n pairs
+        if k < 1:
+            raise ValueError("invalid inputs sizes")
+        _tchk(P, (P, n * G1_BYTES, "P"))                     # binds the device before the table is checked on it
+        if lib.gpbc_check_segments_dev(ctypes.c_void_p(seg_off.data_ptr()), _sz(n), _sz(k), _torch_stream()) < 0:
+            raise ValueError("invalid inputs sizes: " + lib.gpbc_last_error().decode())   # must start at 0, be monotone, end at n
         out = _tnew(P, k, GT_BYTES) if out is None else out
         wsb = lib.gpbc_multi_pair_workspace_bytes(n, k)
         if workspace is None:

@@ -172,6 +172,18 @@ GPBC_KERNEL k_segment_product(const uint8_t *__restrict__ f, const uint64_t *__r
     f12_store(out + j * GPBC_GT_BYTES, acc);
 }
 
+// validation of a device-resident segment table (gpbc_check_segments_dev): bit 0 first entry not zero, bit 1 not monotone,
+// bit 2 last entry is not the number of pairs
+__global__ void __launch_bounds__(BLOCK) k_check_segments(const uint64_t *__restrict__ seg_off, size_t k, size_t n_pairs, int *__restrict__ flag) {
+    size_t j = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (j > k) return;
+    int bad = 0;
+    if (j == 0 && seg_off[0] != 0) bad |= 1;
+    if (j < k && seg_off[j + 1] < seg_off[j]) bad |= 2;
+    if (j == k && seg_off[k] != (uint64_t)n_pairs) bad |= 4;
+    if (bad) atomicOr(flag, bad);
+}
+
 // GT one in gnark bytes: C0.B0.A0 = R mod p, everything else zero
 __global__ void __launch_bounds__(BLOCK) k_gt_is_one(const uint8_t *__restrict__ gt, uint8_t *__restrict__ ok, size_t n) {
     size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -258,6 +270,24 @@ int gpbc_multi_pair_dev(const void *dP, const void *dQ, const uint64_t *d_seg_of
     TRY(check_launch("k_segment_product"));
     profile_mark("k_segment_product", (hipStream_t)stream);
     return gpbc_final_exp_dev(d_gt_out, k, d_gt_out, stream);
+}
+int gpbc_check_segments_dev(const uint64_t *d_seg_off, size_t n_pairs, size_t k, void *stream) {
+    if (!k) return fail(GPBC_ERR_INVALID_ARG, "invalid inputs sizes");
+    if (!d_seg_off) return fail(GPBC_ERR_INVALID_ARG, "null segment table");
+    TRY(bind_device());
+    hipStream_t st = (hipStream_t)stream;
+    DevBuf dFlag;
+    TRY(dFlag.alloc(sizeof(int)));
+    HIP_TRY(hipMemsetAsync(dFlag.p, 0, sizeof(int), st));
+    k_check_segments<<<grid_for(k + 1), BLOCK, 0, st>>>(d_seg_off, k, n_pairs, (int *)dFlag.p);
+    TRY(check_launch("k_check_segments"));
+    int flag = 0;
+    HIP_TRY(hipMemcpyAsync(&flag, dFlag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (flag & 1) return fail(GPBC_ERR_INVALID_ARG, "seg_off[0] must be 0");
+    if (flag & 2) return fail(GPBC_ERR_INVALID_ARG, "segment table not monotone");
+    if (flag & 4) return fail(GPBC_ERR_INVALID_ARG, "seg_off[k] must equal the number of pairs");
+    return GPBC_OK;
 }
 int gpbc_gt_exp_batch_dev(const void *d_x, const void *d_k, size_t n, void *d_out, void *stream) {
     if (!n) return GPBC_OK;

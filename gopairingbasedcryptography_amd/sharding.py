@@ -92,6 +92,14 @@ def aggregate_verify(engine, pk_local, rho_local, sigma_local, H, g1, neg, devic
     point H; rho_local [m,32]: the verifier's random scalars.  Checks  e(sum rho_i pk_i, H) * e(g1, -sum rho_i sigma_i) == 1.
     `neg` negates an affine G2 point on the host (field negation, gnark's G2Affine.Neg).  Returns bool (same on every rank).
     """
+    if isinstance(pk_local, torch.Tensor) and pk_local.is_cuda and getattr(engine, "comm_ranks", lambda: 0)() == _world() and _world() > 1:
+        # HBM-resident shards and a library communicator over the job: local sums, the all-gather of one point per rank and the
+        # sum of the partials all happen inside the C library (gpbc_g1/g2_scalar_mul_sum_dev)
+        A_all = engine.g1_scalar_mul_sum(pk_local, rho_local).cpu().numpy()
+        B_all = engine.g2_scalar_mul_sum(sigma_local, rho_local).cpu().numpy()
+        P = np.concatenate([A_all.reshape(-1), np.asarray(g1).reshape(-1)])
+        Q = np.concatenate([np.asarray(H).reshape(-1), neg(B_all.reshape(-1))])
+        return bool(engine.pairing_check(P, Q))
     A = engine.g1_sum(engine.g1_scalar_mul(pk_local, rho_local))
     B = engine.g2_sum(engine.g2_scalar_mul(sigma_local, rho_local))
     A = A if isinstance(A, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(A))

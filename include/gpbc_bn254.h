@@ -107,6 +107,10 @@ int gpbc_multi_pair(const void *P, const void *Q, const uint64_t *seg_off, size_
 size_t gpbc_multi_pair_workspace_bytes(size_t n_pairs, size_t k);
 int gpbc_multi_pair_dev(const void *dP, const void *dQ, const uint64_t *d_seg_off, size_t n_pairs, size_t k,
                         void *d_gt_out, void *d_workspace, size_t workspace_bytes, void *stream);
+/* Validation of a device-resident table for gpbc_multi_pair_dev (k+1 entries read): one small kernel, synchronises `stream`,
+ * returns GPBC_ERR_INVALID_ARG (first entry not 0, not monotone, last entry != n_pairs) or GPBC_OK.  Optional: the
+ * multi-pairing itself stays asynchronous and safe (clamped) without it. */
+int gpbc_check_segments_dev(const uint64_t *d_seg_off, size_t n_pairs, size_t k, void *stream);
 /* Points and results in device memory, segment table on the HOST (validated like gpbc_multi_pair).  With the table at
  * hand the engine cuts segments (of four or more pairs on average) into chunks of up to 8 pairs whose Miller accumulators
  * SHARE their squarings (F <- F^2 * prod l_p, as gnark's own multi-pairing does): up to 35 % less accumulator work per

@@ -288,6 +288,12 @@ def test_device_pointer_path(eng, synth):
         eng.multi_pair(dP, dQ, np.array([0, 5, 500]))
     with pytest.raises(ValueError, match="invalid inputs sizes"):
         eng.multi_pair(P, Q, np.array([0, 5, 100]))
+    # a segment table that lives in device memory is validated on the device (gpbc_check_segments_dev) before it is used
+    dseg = lambda v: torch.tensor(v, dtype=torch.int64).cuda()
+    assert (eng.multi_pair(dP, dQ, dseg([0, 5, 5, 192])).cpu().numpy() == eng.multi_pair(P, Q, [0, 5, 5, 192])).all()
+    for bad in ([0, 9, 5, 192], [1, 5, 192], [0, 5, 191], [0, 5, 1 << 40]):
+        with pytest.raises(ValueError, match="invalid inputs sizes"):
+            eng.multi_pair(dP, dQ, dseg(bad))
 
 
 def test_cpp_host_mirror_bls_flow(eng, tmp_path):

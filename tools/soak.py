@@ -16,7 +16,7 @@ import oracle_lib  # noqa: E402
 from gopairingbasedcryptography_amd import bn254  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-threads = min(os.cpu_count() or 1, 16)
+threads = min(len(os.sched_getaffinity(0)), 16)
 oracle_lib.build()
 bn254.init(0)
 rng = np.random.default_rng(20261004)

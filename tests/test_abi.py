@@ -133,3 +133,27 @@ def test_wrapper_rejects_malformed_device_arguments():
         with pytest.raises(ValueError):
             call()
         assert True, i
+
+
+def test_device_list_and_collective_entries_fail_loudly_without_gpu(lib):
+    """The multi-device and RCCL entries of the boundary: without a bound gfx950 device every one of them returns a negative
+    status with a message — none aborts, none pretends."""
+    import ctypes
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: tests/cpp/test_multi_device.cpp covers the working paths")
+    devs = (ctypes.c_int * 2)(0, 1)
+    assert lib.gpbc_init_devices(devs, 2) < 0 and b"HIP" in lib.gpbc_last_error() or b"device" in lib.gpbc_last_error()
+    assert lib.gpbc_num_devices() == 0
+    assert lib.gpbc_set_device(0) < 0 and lib.gpbc_get_device() < 0 and lib.gpbc_device_at(0) < 0
+    assert lib.gpbc_comm_init_all() < 0
+    assert lib.gpbc_comm_ranks() == 0 and lib.gpbc_comm_rank() < 0
+    buf = (ctypes.c_uint8 * 128)()
+    assert lib.gpbc_comm_init_rank(buf, 2, 0) < 0                      # no device bound
+    assert lib.gpbc_comm_init_rank(buf, 2, 5) < 0                      # rank out of range
+    assert lib.gpbc_allgather_dev(buf, 128, buf, None) < 0
+    out = np.zeros(64, dtype=np.uint8)
+    pts, ks = np.zeros(64 * 4, dtype=np.uint8), np.zeros(32 * 4, dtype=np.uint8)
+    assert lib.gpbc_g1_scalar_mul_sum(pts.ctypes.data, ks.ctypes.data, ctypes.c_size_t(4), out.ctypes.data) < 0
+    assert lib.gpbc_check_segments_dev(None, ctypes.c_size_t(1), ctypes.c_size_t(1), None) < 0
+    assert lib.gpbc_set_host_sharding(1) == 0 and lib.gpbc_comm_destroy() == 0 and lib.gpbc_shutdown() == 0

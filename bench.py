@@ -349,10 +349,25 @@ def main():
             barrier()
             return out, max_over_ranks(time.perf_counter() - t1)
 
-        def leg_aggregate():
+        def guarded(setup, run):
+            """A leg = rank-local setup (workload generation: the part that can fail on one rank alone) + a run with
+            collectives.  The ranks agree that every setup succeeded before any of them enters the run, so a failure on one
+            rank becomes an error entry on all of them instead of a hang in the next collective."""
+            try:
+                st, err = setup(), None
+            except Exception as exc:                      # noqa: BLE001
+                st, err = None, repr(exc)
+            if not all_ranks_true(err is None):
+                return {"error": err or "setup failed on another rank"}
+            return run(st)
+
+        def setup_aggregate():
             n_total = (1 << 20) // args.config_scale
             lo, hi = sharding.shard_range(n_total, rank, world)
-            inst = wl.aggregate(bn254, hi - lo, dev, start=lo)
+            return n_total, wl.aggregate(bn254, hi - lo, dev, start=lo)
+
+        def run_aggregate(st):
+            n_total, inst = st
             # B = sum rho_i sigma_i over ALL ranks (untimed here; timed in the second figure)
             Bsum = bn254.g2_scalar_mul_sum(inst["sigma"], inst["rho"])
             def literal():                                    # "2^20 G1 scalar-mults + 2 pairings" (BASELINE configs[2])
@@ -380,12 +395,16 @@ def main():
                     "accepts": all_ranks_true(ok and ok2), "rejects_forged": all_ranks_true(rejected),
                     "collective": ("library RCCL all-gather, %d ranks" % bn254.comm_ranks()) if world > 1 else None}
 
-        def leg_bsw07(kind):
+        def setup_bsw07(kind):
             n_total = (1 << 16) // args.config_scale
             lo, hi = sharding.shard_range(n_total, rank, world)
             inst = wl.bsw07_instance(bn254, kind, hi - lo, dev, start=lo)
             plan = bsw07.decrypt_plan(inst["tree"], inst["attrs"])
             folded = bsw07.fold_key(bn254, plan, inst["dj"], inst["dj_prime"])      # once per (key, policy), untimed
+            return kind, n_total, inst, folded
+
+        def run_bsw07(st):
+            kind, n_total, inst, folded = st
             run = lambda: bsw07.decrypt_batch_arrays(bn254, folded, inst["D"], inst["c_tilde"], inst["c"], inst["cy"], inst["cy_prime"])
             run()
             out, t = timed(run)
@@ -395,11 +414,13 @@ def main():
                     "ciphertexts": n_total, "scaling": "strong", "ciphertexts_per_s": n_total / t, "pairs_per_s": pairs / t, "ms": 1e3 * t,
                     "all_messages_recovered": all_ranks_true(bool((out == inst["msgs"]).all()))}
 
-        def leg_afp25():
+        def setup_afp25():
             n_total, Bsz = (1 << 18) // args.config_scale, 256
             per = (n_total // Bsz // world) * Bsz                                   # whole batches per rank
-            n_total = per * world
-            inst = wl.afp25_instance(bn254, Bsz, per, dev, start=rank * per)
+            return per * world, Bsz, per, wl.afp25_instance(bn254, Bsz, per, dev, start=rank * per)
+
+        def run_afp25(st):
+            n_total, Bsz, per, inst = st
             gathered = [None]
             def run():
                 out = afp25.decrypt_batch_arrays(bn254, inst["D"], inst["pi"], inst["sk"], inst["C1"], inst["C2"])
@@ -421,10 +442,11 @@ def main():
             cfg = {}
             if world > 1 and comm_error:
                 cfg["comm_error"] = comm_error
-            for key, fn in (("aggregate_verify_2^20", leg_aggregate), ("bsw07_256of256_2^16", lambda: leg_bsw07("256of256")),
-                            ("bsw07_16x16_2^16", lambda: leg_bsw07("16x16")), ("afp25_2^18", leg_afp25)):
+            for key, setup, run in (("aggregate_verify_2^20", setup_aggregate, run_aggregate),
+                                    ("bsw07_256of256_2^16", lambda: setup_bsw07("256of256"), run_bsw07),
+                                    ("bsw07_16x16_2^16", lambda: setup_bsw07("16x16"), run_bsw07), ("afp25_2^18", setup_afp25, run_afp25)):
                 try:
-                    cfg[key] = fn()
+                    cfg[key] = guarded(setup, run)
                 except Exception as exc:                  # noqa: BLE001
                     cfg[key] = {"error": repr(exc)}
                 torch.cuda.empty_cache()

@@ -62,6 +62,27 @@ int device_count_initialised();
 // from inside a shard run body(0, n) on the calling thread.  Returns the first failing status (its message becomes the
 // caller's gpbc_last_error()).
 int run_sharded(size_t n, size_t min_units, const std::function<int(size_t, size_t)> &body);
+// Host-pointer calls over many units on ONE device: chunks alternate on the slot's two streams.  For chunk c the caller's
+// thread issues upload(c) — a blocking copy from pageable memory, during which the GPU works on chunk c - 1 —, then
+// enqueue(c), then download(c - 1), which waits for chunk c - 1 only.  Transfers of neighbouring chunks thus overlap the
+// kernels; the call returns with everything downloaded and both streams idle.
+int pipe_streams(hipStream_t out[2]);
+template <class Up, class Run, class Down> int pipelined_chunks(size_t n, size_t chunk, Up upload, Run enqueue, Down download) {
+    hipStream_t st[2];
+    TRY(pipe_streams(st));
+    const size_t n_chunks = (n + chunk - 1) / chunk;
+    for (size_t c = 0; c < n_chunks; c++) {
+        const size_t off = c * chunk, m = n - off < chunk ? n - off : chunk;
+        TRY(upload(off, m, st[c & 1]));
+        TRY(enqueue(off, m, st[c & 1]));
+        if (c > 0) TRY(download((c - 1) * chunk, chunk, st[(c - 1) & 1]));
+    }
+    const size_t last = (n_chunks - 1) * chunk;
+    TRY(download(last, n - last, st[(n_chunks - 1) & 1]));
+    HIP_TRY(hipStreamSynchronize(st[0]));
+    HIP_TRY(hipStreamSynchronize(st[1]));
+    return GPBC_OK;
+}
 // RCCL communicator of the current device (gpbc_core.hip): number of ranks (0 = none), this device's rank, all-gather
 int comm_ranks();
 int comm_rank();

@@ -234,9 +234,28 @@ static int sum_dev(bool g2, const void *d_pts, size_t n, void *d_out, void *d_ws
 int gpbc_g1_sum_dev(const void *p, size_t n, void *o, void *w, size_t wb, void *s) { return sum_dev(false, p, n, o, w, wb, s); }
 int gpbc_g2_sum_dev(const void *p, size_t n, void *o, void *w, size_t wb, void *s) { return sum_dev(true, p, n, o, w, wb, s); }
 
+constexpr size_t SMUL_PIPE_CHUNK = 131072;
 static int scalar_mul_one(bool g2, const void *bases, size_t nbase, const void *scalars, size_t n, void *out) {
     TRY(bind_device());
     size_t pt = g2 ? GPBC_G2_BYTES : GPBC_G1_BYTES;
+    if (nbase == n && n >= 2 * SMUL_PIPE_CHUNK) {
+        // one base per scalar, large batch: transfers of neighbouring chunks overlap the kernels (pipelined_chunks)
+        DevBuf dB, dS, dO;
+        TRY(dB.alloc(n * pt)); TRY(dS.alloc(n * GPBC_SCALAR_BYTES)); TRY(dO.alloc(n * pt));
+        int rc = pipelined_chunks(n, SMUL_PIPE_CHUNK,
+            [&](size_t off, size_t m, hipStream_t st) {
+                HIP_TRY(hipMemcpyAsync(dB.u8() + off * pt, (const uint8_t *)bases + off * pt, m * pt, hipMemcpyHostToDevice, st));
+                HIP_TRY(hipMemcpyAsync(dS.u8() + off * GPBC_SCALAR_BYTES, (const uint8_t *)scalars + off * GPBC_SCALAR_BYTES, m * GPBC_SCALAR_BYTES, hipMemcpyHostToDevice, st));
+                return (int)GPBC_OK;
+            },
+            [&](size_t off, size_t m, hipStream_t st) { return scalar_mul_dev(g2, dB.u8() + off * pt, m, dS.u8() + off * GPBC_SCALAR_BYTES, m, dO.u8() + off * pt, st); },
+            [&](size_t off, size_t m, hipStream_t st) {
+                HIP_TRY(hipMemcpyAsync((uint8_t *)out + off * pt, dO.u8() + off * pt, m * pt, hipMemcpyDeviceToHost, st));
+                return (int)GPBC_OK;
+            });
+        if (rc != GPBC_OK) { (void)hipDeviceSynchronize(); return rc; }
+        return GPBC_OK;
+    }
     DevBuf dB, dS, dO;
     TRY(dB.upload(bases, nbase * pt)); TRY(dS.upload(scalars, n * GPBC_SCALAR_BYTES)); TRY(dO.alloc(n * pt));
     TRY(scalar_mul_dev(g2, dB.p, nbase, dS.p, n, dO.p, nullptr));

@@ -353,8 +353,29 @@ int gpbc_final_exp(const void *f, size_t n, void *gt_out) {
         return final_exp_one((const uint8_t *)f + lo * GPBC_GT_BYTES, hi - lo, (uint8_t *)gt_out + lo * GPBC_GT_BYTES);
     });
 }
+constexpr size_t PIPE_CHUNK = 131072;          // pairs per pipelined chunk: 2.5 GB of lines per stream
 static int pair_batch_one(const void *P, const void *Q, size_t n, void *gt_out) {
     TRY(bind_device());
+    if (n >= 2 * PIPE_CHUNK) {
+        // upload / kernels / download of neighbouring chunks overlap on the slot's two streams (pipelined_chunks)
+        DevBuf dP, dQ, dG;
+        TRY(dP.alloc(n * GPBC_G1_BYTES)); TRY(dQ.alloc(n * GPBC_G2_BYTES)); TRY(dG.alloc(n * GPBC_GT_BYTES));
+        int rc = pipelined_chunks(n, PIPE_CHUNK,
+            [&](size_t off, size_t m, hipStream_t st) {
+                HIP_TRY(hipMemcpyAsync(dP.u8() + off * GPBC_G1_BYTES, (const uint8_t *)P + off * GPBC_G1_BYTES, m * GPBC_G1_BYTES, hipMemcpyHostToDevice, st));
+                HIP_TRY(hipMemcpyAsync(dQ.u8() + off * GPBC_G2_BYTES, (const uint8_t *)Q + off * GPBC_G2_BYTES, m * GPBC_G2_BYTES, hipMemcpyHostToDevice, st));
+                return (int)GPBC_OK;
+            },
+            [&](size_t off, size_t m, hipStream_t st) {
+                return gpbc_pair_batch_dev(dP.u8() + off * GPBC_G1_BYTES, dQ.u8() + off * GPBC_G2_BYTES, m, dG.u8() + off * GPBC_GT_BYTES, st);
+            },
+            [&](size_t off, size_t m, hipStream_t st) {
+                HIP_TRY(hipMemcpyAsync((uint8_t *)gt_out + off * GPBC_GT_BYTES, dG.u8() + off * GPBC_GT_BYTES, m * GPBC_GT_BYTES, hipMemcpyDeviceToHost, st));
+                return (int)GPBC_OK;
+            });
+        if (rc != GPBC_OK) { (void)hipDeviceSynchronize(); return rc; }     // nothing may still use the buffers when they are freed
+        return GPBC_OK;
+    }
     DevBuf dP, dQ, dG;
     TRY(dP.upload(P, n * GPBC_G1_BYTES)); TRY(dQ.upload(Q, n * GPBC_G2_BYTES)); TRY(dG.alloc(n * GPBC_GT_BYTES));
     TRY(gpbc_pair_batch_dev(dP.p, dQ.p, n, dG.p, nullptr));

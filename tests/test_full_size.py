@@ -147,3 +147,21 @@ def test_config4_afp25_2_18_identities(eng, oracle, dev):
         p = [oracle.pair_batch(inst[k][j].cpu().numpy(), C1[i]) for i, k in enumerate(("D", "pi", "sk"))]
         want = oracle.gt_div(C2, oracle.gt_mul(oracle.gt_mul(p[0], p[1]), p[2]))[0]
         assert (want == out[j].cpu().numpy()).all() and (want == inst["msgs"][j].cpu().numpy()).all()
+
+
+def test_pipelined_host_entries_match_the_device_path(eng, dev):
+    """Host-pointer calls of 2 x 131072 units or more run as chunks alternating on two streams (upload / kernels / download of
+    neighbouring chunks overlap: csrc/gpbc_common.hpp pipelined_chunks).  300 001 units = two full chunks and a ragged third;
+    the results must be the bytes of the HBM-resident path."""
+    import torch
+    import bench_workloads as w
+    n = 300001
+    g1, g2 = eng.generators()
+    d = lambda a: torch.from_numpy(np.array(a, dtype=np.uint8, copy=True)).to(dev)
+    kP, kQ, ks = (d(w.bench_scalars(t, 7, n)).reshape(n, 32) for t in ("P", "Q", "s"))
+    P, Q = eng.g1_scalar_mul(d(g1), kP), eng.g2_scalar_mul(d(g2), kQ)
+    gt = eng.pair_batch(P, Q)
+    Ph, Qh, kh = P.cpu().numpy(), Q.cpu().numpy(), ks.cpu().numpy()
+    assert (eng.pair_batch(Ph, Qh) == gt.cpu().numpy()).all()
+    assert (eng.g1_scalar_mul(Ph, kh) == eng.g1_scalar_mul(P, ks).cpu().numpy()).all()
+    assert (eng.g2_scalar_mul(Qh, kh) == eng.g2_scalar_mul(Q, ks).cpu().numpy()).all()

@@ -184,7 +184,10 @@ def pair_batch(P, Q, out=None):
     n = P.size // G1_BYTES
     if Q.size // G2_BYTES != n or n == 0:
         raise ValueError("invalid inputs sizes")
-    out = np.empty((n, GT_BYTES), dtype=np.uint8)
+    if out is None:
+        out = np.empty((n, GT_BYTES), dtype=np.uint8)
+    elif not (isinstance(out, np.ndarray) and out.dtype == np.uint8 and out.size == n * GT_BYTES and out.flags["C_CONTIGUOUS"] and out.flags["WRITEABLE"]):
+        raise ValueError("out must be a writable contiguous uint8 array of %d bytes" % (n * GT_BYTES))
     _lib.check(lib.gpbc_pair_batch(_ptr(P), _ptr(Q), _sz(n), _ptr(out)))
     return out
 

@@ -7,11 +7,13 @@
 #define GPBC_COMMON_HPP
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <functional>
 #include <mutex>
+#include <thread>
 #include <vector>
 #include "../../include/gpbc_bn254.h"
 #include "curve29.hip.hpp"
@@ -62,25 +64,58 @@ int device_count_initialised();
 // from inside a shard run body(0, n) on the calling thread.  Returns the first failing status (its message becomes the
 // caller's gpbc_last_error()).
 int run_sharded(size_t n, size_t min_units, const std::function<int(size_t, size_t)> &body);
-// Host-pointer calls over many units on ONE device: chunks alternate on the slot's two streams.  For chunk c the caller's
-// thread issues upload(c) — a blocking copy from pageable memory, during which the GPU works on chunk c - 1 —, then
-// enqueue(c), then download(c - 1), which waits for chunk c - 1 only.  Transfers of neighbouring chunks thus overlap the
-// kernels; the call returns with everything downloaded and both streams idle.
-int pipe_streams(hipStream_t out[2]);
+// Host-pointer calls over many units on ONE device: chunks alternate on the slot's two compute streams while a helper thread
+// drains the results on a third.  The caller's thread runs upload(c) — a blocking copy from pageable memory, during which the
+// GPU works on earlier chunks — then enqueue(c) and records an event; the helper waits for that event on the download stream
+// and copies chunk c back (a blocking copy again, but nobody queues behind it).  The compute streams never wait for a
+// download, so the call takes about upload(first) + kernels + download(last); it returns with everything downloaded and all
+// three streams idle.  current_slot / set_slot let the helper thread adopt the caller's device slot.
+int pipe_streams(hipStream_t out[3]);
+int current_slot();
+int set_slot(int index);
 template <class Up, class Run, class Down> int pipelined_chunks(size_t n, size_t chunk, Up upload, Run enqueue, Down download) {
-    hipStream_t st[2];
+    hipStream_t st[3];
     TRY(pipe_streams(st));
     const size_t n_chunks = (n + chunk - 1) / chunk;
-    for (size_t c = 0; c < n_chunks; c++) {
+    std::vector<hipEvent_t> ev(n_chunks, nullptr);
+    for (auto &e : ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t recorded = 0;
+    bool abort_all = false;
+    int rc_down = GPBC_OK;
+    char err_down[512] = "";
+    const int slot = current_slot();
+    std::thread drain([&]() {
+        if (set_slot(slot) != GPBC_OK || bind_device() != GPBC_OK) { rc_down = GPBC_ERR_HIP; snprintf(err_down, sizeof err_down, "%s", g_err); return; }
+        for (size_t c = 0; c < n_chunks; c++) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return recorded > c || abort_all; });
+                if (recorded <= c) return;
+            }
+            const size_t off = c * chunk, m = n - off < chunk ? n - off : chunk;
+            int rc = hipStreamWaitEvent(st[2], ev[c], 0) == hipSuccess ? download(off, m, st[2]) : fail(GPBC_ERR_HIP, "hipStreamWaitEvent failed");
+            if (rc == GPBC_OK && hipStreamSynchronize(st[2]) != hipSuccess) rc = fail(GPBC_ERR_HIP, "hipStreamSynchronize (download stream) failed");
+            if (rc != GPBC_OK) { rc_down = rc; snprintf(err_down, sizeof err_down, "%s", g_err); return; }
+        }
+    });
+    int rc = GPBC_OK;
+    for (size_t c = 0; c < n_chunks && rc == GPBC_OK; c++) {
         const size_t off = c * chunk, m = n - off < chunk ? n - off : chunk;
-        TRY(upload(off, m, st[c & 1]));
-        TRY(enqueue(off, m, st[c & 1]));
-        if (c > 0) TRY(download((c - 1) * chunk, chunk, st[(c - 1) & 1]));
+        rc = upload(off, m, st[c & 1]);
+        if (rc == GPBC_OK) rc = enqueue(off, m, st[c & 1]);
+        if (rc == GPBC_OK && hipEventRecord(ev[c], st[c & 1]) != hipSuccess) rc = fail(GPBC_ERR_HIP, "hipEventRecord failed");
+        if (rc == GPBC_OK) { std::lock_guard<std::mutex> lk(mu); recorded = c + 1; }
+        cv.notify_all();
     }
-    const size_t last = (n_chunks - 1) * chunk;
-    TRY(download(last, n - last, st[(n_chunks - 1) & 1]));
-    HIP_TRY(hipStreamSynchronize(st[0]));
-    HIP_TRY(hipStreamSynchronize(st[1]));
+    if (rc != GPBC_OK) { std::lock_guard<std::mutex> lk(mu); abort_all = true; }
+    cv.notify_all();
+    drain.join();
+    (void)hipStreamSynchronize(st[0]); (void)hipStreamSynchronize(st[1]); (void)hipStreamSynchronize(st[2]);
+    for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+    if (rc != GPBC_OK) return rc;
+    if (rc_down != GPBC_OK) return fail(rc_down, "%s", err_down);
     return GPBC_OK;
 }
 // RCCL communicator of the current device (gpbc_core.hip): number of ranks (0 = none), this device's rank, all-gather

@@ -25,7 +25,7 @@ struct DeviceCtx {
     int hip = -1;                 // HIP ordinal
     std::mutex ws_seq;            // held while a call enqueues kernels that share this device's stream workspace
     ncclComm_t comm = nullptr;    // RCCL communicator of this device (rank = comm_rank of comm_ranks), or null
-    hipStream_t pipe[2] = {nullptr, nullptr};   // the two streams large host-pointer calls alternate their chunks on
+    hipStream_t pipe[3] = {nullptr, nullptr, nullptr};   // large host-pointer calls: two compute streams + one download stream
     std::mutex pipe_mu;
 };
 static DeviceCtx g_ctx[MAX_DEVICES];
@@ -53,21 +53,23 @@ std::mutex &ws_seq_mutex() {
     int n = g_ndev.load(), i = cur_index();
     return g_ctx[(n > 0 && i < n) ? i : 0].ws_seq;
 }
-// Two non-blocking streams per bound device slot, created on first use: a large host-pointer call cuts its batch into chunks
-// and alternates them, so that the upload of chunk c + 1 and the download of chunk c - 1 overlap the kernels of chunk c.
-int pipe_streams(hipStream_t out[2]) {
+// Three non-blocking streams per bound device slot, created on first use: a large host-pointer call cuts its batch into
+// chunks, alternates them on the first two and drains results on the third (gpbc_common.hpp: pipelined_chunks).
+int current_slot() { return cur_index(); }
+int set_slot(int index) { return gpbc_set_device(index); }
+int pipe_streams(hipStream_t out[3]) {
     const int n = g_ndev.load(), i = cur_index();
     if (n <= 0 || i >= n) return fail(GPBC_ERR_NO_DEVICE, "gpbc_init() has not bound a HIP device");
     DeviceCtx &c = g_ctx[i];
     std::lock_guard<std::mutex> lk(c.pipe_mu);
-    for (int k = 0; k < 2; k++)
+    for (int k = 0; k < 3; k++)
         if (!c.pipe[k]) HIP_TRY(hipStreamCreateWithFlags(&c.pipe[k], hipStreamNonBlocking));
-    out[0] = c.pipe[0]; out[1] = c.pipe[1];
+    out[0] = c.pipe[0]; out[1] = c.pipe[1]; out[2] = c.pipe[2];
     return GPBC_OK;
 }
 static void free_pipe_streams() {
     for (int i = 0; i < MAX_DEVICES; i++)
-        for (int k = 0; k < 2; k++)
+        for (int k = 0; k < 3; k++)
             if (g_ctx[i].pipe[k]) {
                 if (g_ctx[i].hip >= 0) (void)hipSetDevice(g_ctx[i].hip);
                 (void)hipStreamSynchronize(g_ctx[i].pipe[k]);

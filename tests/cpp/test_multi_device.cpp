@@ -122,6 +122,25 @@ int main() {
         EXPECT(S7.Equal(want7));
     }
     printf("sharded host entries identical to one device: %zu pairings, %zu ragged segments, scalar mults, GT, wire, sums\n", N, k);
+    {   // a batch large enough for every shard to run PIPELINED (>= 2 x 131072 units per device: chunks on two streams, results
+        // drained by a helper thread) against the same batch in slices small enough for the plain upload -> compute -> download
+        const size_t NB = (size_t)nd * 270000 + 17;
+        std::vector<Scalar> ka(NB), kb(NB);
+        for (size_t i = 0; i < NB; i++) { ka[i] = Scalar(0x9E3779B97F4A7C15ull * (i + 11)); kb[i] = Scalar(0xC2B2AE3D27D4EB4Full * (i + 13)); }
+        std::vector<G1Affine> PB = G1ScalarMultiplicationBatch({g1}, ka);
+        std::vector<G2Affine> QB = G2ScalarMultiplicationBatch({g2}, kb);
+        std::vector<GT> big = PairBatch(PB, QB), ref(NB);
+        std::vector<G1Affine> PK = G1ScalarMultiplicationBatch(PB, kb), PKref(NB);          // one base per scalar: pipelined as well
+        check(gpbc_set_host_sharding(0));
+        for (size_t off = 0; off < NB; off += 100000) {
+            const size_t m = NB - off < 100000 ? NB - off : 100000;
+            check(gpbc_pair_batch(&PB[off], &QB[off], m, &ref[off]));
+            check(gpbc_g1_scalar_mul_batch(&PB[off], m, &kb[off], m, &PKref[off]));
+        }
+        check(gpbc_set_host_sharding(1));
+        EXPECT(same(big, ref) && same(PK, PKref));
+        printf("pipelined + sharded host calls identical to plain ones: %zu pairings and G1 scalar multiplications\n", NB);
+    }
 
     // ---- 2. one host thread per device slot, device-resident buffers, own stream
     {

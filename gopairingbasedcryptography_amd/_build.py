@@ -1,6 +1,6 @@
 """Compile libgpbc_bn254.so for gfx950 with hipcc (in-tree, next to this file).
 
-Four translation units (csrc/gpbc_core.hip, gpbc_pairing.hip, gpbc_curve.hip, gpbc_wire.hip) are compiled in parallel and
+Five translation units (csrc/gpbc_core.hip, gpbc_pairing.hip, gpbc_curve.hip, gpbc_wire.hip, gpbc_msm.hip) are compiled in parallel and
 linked into one shared library; every unit carries its own device code (no relocatable device code is needed: kernels are
 launched from the unit that defines them)."""
 import hashlib
@@ -13,9 +13,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgpbc_bn254.so")
 STAMP = os.path.join(HERE, "libgpbc_bn254.buildhash")
-SOURCES = ["gpbc_core.hip", "gpbc_pairing.hip", "gpbc_curve.hip", "gpbc_wire.hip"]
+SOURCES = ["gpbc_core.hip", "gpbc_pairing.hip", "gpbc_curve.hip", "gpbc_wire.hip", "gpbc_msm.hip"]
 HEADERS = ["gpbc_common.hpp", "fe29.hip.hpp", "tower29.hip.hpp", "tower29_pair.hip.hpp", "curve29.hip.hpp", "pairing29.hip.hpp", "pairing29_pair.hip.hpp",
-           "wire29.hip.hpp", "h2c29.hip.hpp", "bn254_constants.hip.hpp", "bn254_constants29.hip.hpp"]
+           "wire29.hip.hpp", "h2c29.hip.hpp", "msm29.hip.hpp", "bn254_constants.hip.hpp", "bn254_constants29.hip.hpp"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC"]
 
 

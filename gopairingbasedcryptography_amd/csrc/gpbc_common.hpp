@@ -118,6 +118,10 @@ template <class Up, class Run, class Down> int pipelined_chunks(size_t n, size_t
     if (rc_down != GPBC_OK) return fail(rc_down, "%s", err_down);
     return GPBC_OK;
 }
+// Bucket (Pippenger) multi-scalar multiplication over variable bases (gpbc_msm.hip): sum_i [s_i] P_i, n terms in device memory,
+// one affine point out; asynchronous on `st`.  Used by the scalar_mul_sum entries from MSM_MIN_TERMS terms on.
+constexpr size_t MSM_MIN_TERMS = 16384;
+int msm_dev(bool g2, const void *d_bases, const void *d_scalars, size_t n, void *d_out, hipStream_t st);
 // RCCL communicator of the current device (gpbc_core.hip): number of ranks (0 = none), this device's rank, all-gather
 int comm_ranks();
 int comm_rank();

@@ -364,6 +364,10 @@ static int scalar_mul_sum_host(bool g2, const void *bases, const void *scalars, 
         const size_t m = hi - lo;
         DevBuf dB, dS, dM, dW;
         TRY(dB.upload((const uint8_t *)bases + lo * pt, m * pt)); TRY(dS.upload((const uint8_t *)scalars + lo * GPBC_SCALAR_BYTES, m * GPBC_SCALAR_BYTES));
+        if (m >= MSM_MIN_TERMS) {                                  // bucket method instead of m independent multiplications
+            TRY(msm_dev(g2, dB.p, dS.p, m, d_out, nullptr));
+            return sync_default();
+        }
         TRY(dM.alloc(m * pt));
         TRY(scalar_mul_dev(g2, dB.p, m, dS.p, m, dM.p, nullptr));
         const size_t wsb = gpbc_sum_workspace_bytes(m, g2);
@@ -381,16 +385,20 @@ static int scalar_mul_sum_dev(bool g2, const void *d_bases, const void *d_scalar
     hipStream_t st = (hipStream_t)stream;
     const size_t pt = g2 ? GPBC_G2_BYTES : GPBC_G1_BYTES;
     const int ranks = comm_ranks();
-    const size_t wsb_local = gpbc_sum_workspace_bytes(n, g2), wsb_all = gpbc_sum_workspace_bytes((size_t)(ranks > 1 ? ranks : 1), g2);
+    const bool bucket = n >= MSM_MIN_TERMS;                       // Pippenger instead of n independent multiplications + a sum tree
+    const size_t wsb_local = bucket ? 0 : gpbc_sum_workspace_bytes(n, g2), wsb_all = gpbc_sum_workspace_bytes((size_t)(ranks > 1 ? ranks : 1), g2);
     // one stream-ordered scratch block: products | local tree workspace | local sum | gathered sums | final tree workspace
-    const size_t total = n * pt + wsb_local + pt + (size_t)(ranks > 1 ? ranks : 1) * pt + wsb_all;
+    const size_t total = (bucket ? 0 : n * pt) + wsb_local + pt + (size_t)(ranks > 1 ? ranks : 1) * pt + wsb_all;
     uint8_t *mem = nullptr;
     HIP_TRY(hipMallocAsync((void **)&mem, total, st));
-    uint8_t *prod = mem, *ws1 = prod + n * pt, *local = ws1 + wsb_local, *all = local + pt, *ws2 = all + (size_t)(ranks > 1 ? ranks : 1) * pt;
+    uint8_t *prod = mem, *ws1 = prod + (bucket ? 0 : n * pt), *local = ws1 + wsb_local, *all = local + pt, *ws2 = all + (size_t)(ranks > 1 ? ranks : 1) * pt;
     int rc = GPBC_OK;
-    if (n) rc = scalar_mul_dev(g2, d_bases, n, d_scalars, n, prod, stream);
     uint8_t *local_out = ranks > 1 ? local : (uint8_t *)d_out;
-    if (rc == GPBC_OK) rc = sum_dev(g2, prod, n, local_out, ws1, wsb_local, stream);
+    if (bucket) rc = msm_dev(g2, d_bases, d_scalars, n, local_out, st);
+    else {
+        if (n) rc = scalar_mul_dev(g2, d_bases, n, d_scalars, n, prod, stream);
+        if (rc == GPBC_OK) rc = sum_dev(g2, prod, n, local_out, ws1, wsb_local, stream);
+    }
     if (rc == GPBC_OK && ranks > 1) {
         rc = comm_allgather(local, pt, all, st);
         if (rc == GPBC_OK) rc = sum_dev(g2, all, (size_t)ranks, d_out, ws2, wsb_all, stream);

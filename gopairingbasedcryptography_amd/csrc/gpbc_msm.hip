@@ -1,0 +1,197 @@
+// libgpbc_bn254.so, unit 5 of 5: bucket (Pippenger) multi-scalar multiplication over variable bases (csrc/msm29.hip.hpp) —
+// the engine behind gpbc_g1/g2_scalar_mul_sum(_dev) from 16 384 terms on.  gfx950 only.
+//
+// Device plan for n terms, c-bit windows (c = 16 from 2^17 terms on, else 12), W = ceil(256 / c), M = W * 2^c bucket keys:
+//   k_msm_count      one lane per term: its W digits -> histogram of the keys (atomics in L2; digit 0 and infinite bases skipped)
+//   k_scan_*         exclusive prefix sum of the histogram (three small kernels)
+//   k_msm_scatter    one lane per term again: term index into its slot of every bucket it belongs to
+//   k_msm_buckets    one lane per bucket: mixed additions of its terms (gathered 64 / 128-byte affine points) -> Jacobian row
+//   k_msm_groups     one lane per (window, 16 digits): running-sum reduction + one multiplication by a 16-bit integer
+//   k_msm_rows_sum   fan-in-64 sums of the group rows of a window (two levels)
+//   k_msm_finish     one lane: Horner over the windows, affine result in gnark's layout
+// All scratch is one stream-ordered allocation; the call is asynchronous on `stream`.
+#include "gpbc_common.hpp"
+#include "msm29.hip.hpp"
+
+constexpr int SCAN_BLOCK = 256, SCAN_ITEMS = 4, SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
+
+template <class F> __device__ __forceinline__ bool base_is_inf(const uint8_t *p) {
+    if constexpr (sizeof(F) == sizeof(Fe)) return g1_bytes_inf(p); else return g2_bytes_inf(p);
+}
+template <class F> __device__ __forceinline__ AffP<F> base_load(const uint8_t *p) {
+    if constexpr (sizeof(F) == sizeof(Fe)) return g1_load_aff(p); else return g2_load_aff(p);
+}
+
+template <class F, bool SCATTER>
+__global__ void __launch_bounds__(BLOCK) k_msm_keys(const uint8_t *__restrict__ bases, const uint8_t *__restrict__ scalars, size_t n, int c, int W,
+                                                   uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets, uint32_t *__restrict__ idx) {
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    constexpr size_t PT = sizeof(F) == sizeof(Fe) ? GPBC_G1_BYTES : GPBC_G2_BYTES;
+    if (base_is_inf<F>(bases + i * PT)) return;
+    uint32_t k[8];
+    load_scalar(k, scalars + i * GPBC_SCALAR_BYTES);
+    for (int w = 0; w < W; w++) {
+        const uint32_t d = msm_digit(k, w, c);
+        if (!d) continue;
+        const uint32_t key = ((uint32_t)w << c) | d;
+        const uint32_t pos = atomicAdd(&counts[key], 1u);
+        if (SCATTER) idx[offsets[key] + pos] = (uint32_t)i;
+    }
+}
+
+// exclusive scan of m counters: per-tile scan + tile totals, scan of the totals (one block), add-back
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_tiles(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint32_t *__restrict__ tile_sum, size_t m) {
+    __shared__ uint32_t sh[SCAN_BLOCK];
+    const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS], s = 0;
+    for (int j = 0; j < SCAN_ITEMS; j++) { v[j] = base + j < m ? in[base + j] : 0; s += v[j]; }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < SCAN_BLOCK; off <<= 1) {
+        uint32_t t = threadIdx.x >= (unsigned)off ? sh[threadIdx.x - off] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t run = sh[threadIdx.x] - s;                      // exclusive prefix of this thread within the tile
+    for (int j = 0; j < SCAN_ITEMS; j++) { if (base + j < m) out[base + j] = run; run += v[j]; }
+    if (threadIdx.x == SCAN_BLOCK - 1) tile_sum[blockIdx.x] = sh[threadIdx.x];
+}
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_tops(uint32_t *__restrict__ tile_sum, size_t n_tiles, uint32_t *__restrict__ total) {
+    __shared__ uint32_t sh[SCAN_BLOCK];
+    uint32_t carry = 0;
+    for (size_t b = 0; b < n_tiles; b += SCAN_BLOCK) {
+        const size_t i = b + threadIdx.x;
+        const uint32_t v = i < n_tiles ? tile_sum[i] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < SCAN_BLOCK; off <<= 1) {
+            uint32_t t = threadIdx.x >= (unsigned)off ? sh[threadIdx.x - off] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < n_tiles) tile_sum[i] = carry + sh[threadIdx.x] - v;
+        const uint32_t block_total = sh[SCAN_BLOCK - 1];
+        __syncthreads();
+        carry += block_total;
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_add(uint32_t *__restrict__ out, const uint32_t *__restrict__ tile_sum, size_t m, const uint32_t *__restrict__ total) {
+    const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+    const uint32_t add = tile_sum[blockIdx.x];
+    for (int j = 0; j < SCAN_ITEMS; j++) if (base + j < m) out[base + j] += add;
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[m] = *total;   // sentinel: offsets[m] = number of (term, window) entries
+}
+
+template <class F> __global__ void __launch_bounds__(BLOCK, sizeof(F) == sizeof(Fe) ? GPBC_WAVES_G1 : GPBC_WAVES_PER_SIMD)
+k_msm_buckets(const uint8_t *__restrict__ bases, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ idx, int c, size_t M, int32_t *__restrict__ rows) {
+    size_t key = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (key >= M) return;
+    constexpr size_t PT = sizeof(F) == sizeof(Fe) ? GPBC_G1_BYTES : GPBC_G2_BYTES;
+    JacP<F> acc;
+    if ((key & (((size_t)1 << c) - 1)) == 0) jac_set_inf(acc);               // digit 0 has no bucket
+    else msm_bucket_sum(acc, offsets[key], offsets[key + 1], [&](size_t j) { return base_load<F>(bases + (size_t)idx[j] * PT); });
+    jac_row_store(rows + key * JacRow<F>::DWORDS, acc);
+}
+template <class F> __global__ void __launch_bounds__(BLOCK, sizeof(F) == sizeof(Fe) ? GPBC_WAVES_G1 : GPBC_WAVES_PER_SIMD)
+k_msm_groups(const int32_t *__restrict__ buckets, int c, size_t n_groups_total, int32_t *__restrict__ out) {
+    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= n_groups_total) return;
+    const size_t groups_per_window = ((size_t)1 << c) / MSM_GROUP;
+    const size_t w = t / groups_per_window, g = t % groups_per_window;
+    const uint32_t lo = (uint32_t)(g * MSM_GROUP), hi = lo + MSM_GROUP - 1;
+    const int32_t *win = buckets + (w << c) * JacRow<F>::DWORDS;
+    JacP<F> r;
+    msm_group_reduce(r, lo ? lo : 1u, hi, [&](uint32_t d) { JacP<F> b; jac_row_load(b, win + (size_t)d * JacRow<F>::DWORDS); return b; });
+    jac_row_store(out + t * JacRow<F>::DWORDS, r);
+}
+// out[t] = sum_{j < fan} in[t * fan + j]
+template <class F> __global__ void __launch_bounds__(BLOCK, sizeof(F) == sizeof(Fe) ? GPBC_WAVES_G1 : GPBC_WAVES_PER_SIMD)
+k_msm_rows_sum(const int32_t *__restrict__ in, size_t n_out, size_t fan, int32_t *__restrict__ out) {
+    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= n_out) return;
+    JacP<F> acc, b, s;
+    jac_set_inf(acc);
+    for (size_t j = 0; j < fan; j++) {
+        jac_row_load(b, in + (t * fan + j) * JacRow<F>::DWORDS);
+        jac_add(s, acc, b);
+        acc = s;
+    }
+    jac_row_store(out + t * JacRow<F>::DWORDS, acc);
+}
+template <class F> __global__ void __launch_bounds__(BLOCK) k_msm_finish(const int32_t *__restrict__ window_sums, int c, int W, uint8_t *__restrict__ out) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    JacP<F> acc, s;
+    jac_row_load(acc, window_sums + (size_t)(W - 1) * JacRow<F>::DWORDS);
+    for (int w = W - 2; w >= 0; w--) {
+        jac_row_load(s, window_sums + (size_t)w * JacRow<F>::DWORDS);
+        msm_horner_step(acc, s, c);
+    }
+    AffP<F> r;
+    jac_to_affine(r, acc);
+    if constexpr (sizeof(F) == sizeof(Fe)) g1_store_aff(out, r); else g2_store_aff(out, r);
+}
+
+struct MsmPlan { int c, W; size_t M, n_groups, rows_l1, bytes; size_t off_counts, off_offsets, off_tiles, off_total, off_idx, off_buckets, off_groups, off_l1, off_l2; };
+static MsmPlan msm_plan(bool g2, size_t n) {
+    MsmPlan p;
+    p.c = n >= ((size_t)1 << 17) ? 16 : 12;
+    p.W = (256 + p.c - 1) / p.c;
+    p.M = (size_t)p.W << p.c;
+    p.n_groups = p.M / MSM_GROUP;
+    const size_t row = (g2 ? JacRow<F2>::DWORDS : JacRow<Fe>::DWORDS) * sizeof(int32_t);
+    const size_t gpw = ((size_t)1 << p.c) / MSM_GROUP;                 // groups per window: 4096 (c = 16) or 256 (c = 12)
+    p.rows_l1 = (size_t)p.W * (gpw / 64);                              // after one fan-in-64 level: 64 or 4 rows per window
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t o = 0;
+    p.off_counts = o;  o += up(p.M * 4);
+    p.off_offsets = o; o += up((p.M + 1) * 4);
+    p.off_tiles = o;   o += up(((p.M + SCAN_TILE - 1) / SCAN_TILE) * 4);
+    p.off_total = o;   o += 256;
+    p.off_idx = o;     o += up(n * (size_t)p.W * 4);
+    p.off_buckets = o; o += up(p.M * row);
+    p.off_groups = o;  o += up(p.n_groups * row);
+    p.off_l1 = o;      o += up(p.rows_l1 * row);
+    p.off_l2 = o;      o += up((size_t)p.W * row);
+    p.bytes = o;
+    return p;
+}
+
+template <class F> static int msm_run(const uint8_t *d_bases, const uint8_t *d_scalars, size_t n, uint8_t *d_out, hipStream_t st) {
+    constexpr bool G2 = sizeof(F) != sizeof(Fe);
+    const MsmPlan p = msm_plan(G2, n);
+    if (n * (size_t)p.W >= ((size_t)1 << 32)) return fail(GPBC_ERR_INVALID_ARG, "MSM of %zu terms exceeds the 32-bit index space of one call", n);
+    uint8_t *mem = nullptr;
+    HIP_TRY(hipMallocAsync((void **)&mem, p.bytes, st));
+    uint32_t *counts = (uint32_t *)(mem + p.off_counts), *offsets = (uint32_t *)(mem + p.off_offsets), *tiles = (uint32_t *)(mem + p.off_tiles);
+    uint32_t *total = (uint32_t *)(mem + p.off_total), *idx = (uint32_t *)(mem + p.off_idx);
+    int32_t *buckets = (int32_t *)(mem + p.off_buckets), *groups = (int32_t *)(mem + p.off_groups), *l1 = (int32_t *)(mem + p.off_l1), *l2 = (int32_t *)(mem + p.off_l2);
+    const size_t n_tiles = (p.M + SCAN_TILE - 1) / SCAN_TILE;
+    const size_t gpw = ((size_t)1 << p.c) / MSM_GROUP;
+    int rc = GPBC_OK;
+    auto step = [&](const char *name) { if (rc == GPBC_OK) { rc = check_launch(name); profile_mark(name, st); } };
+    if (hipMemsetAsync(counts, 0, p.M * 4, st) != hipSuccess) rc = fail(GPBC_ERR_HIP, "hipMemsetAsync failed");
+    if (rc == GPBC_OK) { k_msm_keys<F, false><<<grid_for(n), BLOCK, 0, st>>>(d_bases, d_scalars, n, p.c, p.W, counts, nullptr, nullptr); step(G2 ? "k_msm_count_g2" : "k_msm_count_g1"); }
+    if (rc == GPBC_OK) { k_scan_tiles<<<(unsigned)n_tiles, SCAN_BLOCK, 0, st>>>(counts, offsets, tiles, p.M); step("k_scan_tiles"); }
+    if (rc == GPBC_OK) { k_scan_tops<<<1, SCAN_BLOCK, 0, st>>>(tiles, n_tiles, total); step("k_scan_tops"); }
+    if (rc == GPBC_OK) { k_scan_add<<<(unsigned)n_tiles, SCAN_BLOCK, 0, st>>>(offsets, tiles, p.M, total); step("k_scan_add"); }
+    if (rc == GPBC_OK && hipMemsetAsync(counts, 0, p.M * 4, st) != hipSuccess) rc = fail(GPBC_ERR_HIP, "hipMemsetAsync failed");
+    if (rc == GPBC_OK) { k_msm_keys<F, true><<<grid_for(n), BLOCK, 0, st>>>(d_bases, d_scalars, n, p.c, p.W, counts, offsets, idx); step(G2 ? "k_msm_scatter_g2" : "k_msm_scatter_g1"); }
+    if (rc == GPBC_OK) { k_msm_buckets<F><<<grid_for(p.M), BLOCK, 0, st>>>(d_bases, offsets, idx, p.c, p.M, buckets); step(G2 ? "k_msm_buckets_g2" : "k_msm_buckets_g1"); }
+    if (rc == GPBC_OK) { k_msm_groups<F><<<grid_for(p.n_groups), BLOCK, 0, st>>>(buckets, p.c, p.n_groups, groups); step(G2 ? "k_msm_groups_g2" : "k_msm_groups_g1"); }
+    if (rc == GPBC_OK) { k_msm_rows_sum<F><<<grid_for(p.rows_l1), BLOCK, 0, st>>>(groups, p.rows_l1, 64, l1); step(G2 ? "k_msm_rows_sum_g2" : "k_msm_rows_sum_g1"); }
+    if (rc == GPBC_OK) { k_msm_rows_sum<F><<<grid_for((size_t)p.W), BLOCK, 0, st>>>(l1, (size_t)p.W, gpw / 64, l2); step(G2 ? "k_msm_rows_sum_g2" : "k_msm_rows_sum_g1"); }
+    if (rc == GPBC_OK) { k_msm_finish<F><<<1, BLOCK, 0, st>>>(l2, p.c, p.W, d_out); step(G2 ? "k_msm_finish_g2" : "k_msm_finish_g1"); }
+    (void)hipFreeAsync(mem, st);
+    return rc;
+}
+
+// sum_i [s_i] P_i over n >= MSM_MIN_TERMS terms in device memory, result (one affine point, gnark layout) at d_out
+int msm_dev(bool g2, const void *d_bases, const void *d_scalars, size_t n, void *d_out, hipStream_t st) {
+    TRY(bind_device());
+    return g2 ? msm_run<F2>((const uint8_t *)d_bases, (const uint8_t *)d_scalars, n, (uint8_t *)d_out, st)
+              : msm_run<Fe>((const uint8_t *)d_bases, (const uint8_t *)d_scalars, n, (uint8_t *)d_out, st);
+}

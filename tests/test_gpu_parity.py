@@ -667,3 +667,29 @@ def test_tiny_and_empty_batches(eng, oracle):
     assert eng.g1_marshal(empty).shape == (0, 64) and eng.g2_unmarshal(empty)[0].shape == (0, 128)
     assert eng.map_to_g2(empty).shape == (0, 128) and eng.gt_marshal(empty).shape == (0, 384)
     assert eng.g1_scalar_mul(empty, empty).shape[0] == 0
+
+
+def test_bucket_msm_against_scalar_multiplications(eng, oracle):
+    """gpbc_g1/g2_scalar_mul_sum from 16 384 terms on runs the bucket (Pippenger) method of csrc/gpbc_msm.hip: both window sizes
+    (12-bit below 2^17 terms, 16-bit from there), full-width scalars (values >= r included), zero scalars, points at infinity
+    and repeated bases, against the sum of the engine's independent scalar multiplications and, on the small case, the oracle."""
+    import torch
+    g1, g2 = eng.generators()
+    rng = np.random.default_rng(1234)
+    for n in (20001, 140003):
+        K = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+        K[0] = 0; K[1] = 255; K[2, 1:] = 0; K[5, 16:] = 0
+        kb = rng.integers(0, 256, size=(n, 32), dtype=np.uint8); kb[:, 31] &= 0x1F
+        dK, dkb = torch.from_numpy(K).cuda(), torch.from_numpy(kb).cuda()
+        for gen, mul, summ, msm, w in ((g1, eng.g1_scalar_mul, eng.g1_sum, eng.g1_scalar_mul_sum, 64), (g2, eng.g2_scalar_mul, eng.g2_sum, eng.g2_scalar_mul_sum, 128)):
+            B = mul(torch.from_numpy(gen).cuda(), dkb)
+            B[3] = 0                                                  # infinity
+            B[7] = B[6]; dK[7] = dK[6]                               # same base and scalar twice
+            want = summ(mul(B, dK)).cpu().numpy()
+            got = msm(B, dK).cpu().numpy()
+            assert (got == want).all(), (n, w)
+            assert (msm(B.cpu().numpy(), dK.cpu().numpy()) == want).all(), (n, w, "host entry")
+            if n < 50000:
+                o_want = np.asarray(oracle.g1_sum(oracle.g1_scalar_mul(B.cpu().numpy(), dK.cpu().numpy(), threads=16)) if w == 64 else
+                                    oracle.g2_sum(oracle.g2_scalar_mul(B.cpu().numpy(), dK.cpu().numpy(), threads=16))).reshape(-1)
+                assert (got == o_want).all(), (n, w, "oracle")

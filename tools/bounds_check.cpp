@@ -13,6 +13,7 @@
 #include "../gopairingbasedcryptography_amd/csrc/pairing29_pair.hip.hpp"
 #include "../gopairingbasedcryptography_amd/csrc/wire29.hip.hpp"
 #include "../gopairingbasedcryptography_amd/csrc/h2c29.hip.hpp"
+#include "../gopairingbasedcryptography_amd/csrc/msm29.hip.hpp"
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -67,6 +68,40 @@ template <class F, class LoadA, class StoreA> static void smul_batch(const uint8
     }
 }
 
+// Bucket MSM exactly as csrc/gpbc_msm.hip runs it — the same per-lane pieces of msm29.hip.hpp in the same order (bucket sums by
+// mixed additions, group reduction with the small multiplication, fan-in sums, Horner over the windows) — with the points kept as
+// objects so that their tracked intervals flow from step to step.  out = sum_i [K_i] B_i (affine, gnark layout).
+template <class F, class LoadA, class StoreA> static void msm_host(const uint8_t *B, const uint8_t *K, size_t n, int c, uint8_t *out, size_t pt, LoadA ld, StoreA st) {
+    const int W = (256 + c - 1) / c;
+    const size_t nb = (size_t)1 << c;
+    std::vector<std::vector<size_t>> members((size_t)W * nb);
+    for (size_t i = 0; i < n; i++) {
+        if (bytes_all_zero(B + pt * i, (int)(pt / 4))) continue;
+        uint32_t k[8]; memcpy(k, K + 32 * i, 32);
+        for (int w = 0; w < W; w++) { uint32_t d = msm_digit(k, w, c); if (d) members[(size_t)w * nb + d].push_back(i); }
+    }
+    std::vector<JacP<F>> buckets((size_t)W * nb);
+    for (size_t key = 0; key < buckets.size(); key++) {
+        const auto &m = members[key];
+        msm_bucket_sum(buckets[key], 0, m.size(), [&](size_t j) { return ld(B + pt * m[j]); });
+    }
+    const size_t gpw = nb >= (size_t)MSM_GROUP ? nb / MSM_GROUP : 1, gsz = nb >= (size_t)MSM_GROUP ? MSM_GROUP : nb;
+    std::vector<JacP<F>> wsum(W);
+    for (int w = 0; w < W; w++) {
+        JacP<F> acc, s; jac_set_inf(acc);
+        for (size_t g = 0; g < gpw; g++) {
+            JacP<F> r;
+            uint32_t lo = (uint32_t)(g * gsz), hi = lo + (uint32_t)gsz - 1;
+            msm_group_reduce(r, lo ? lo : 1u, hi, [&](uint32_t d) { return buckets[(size_t)w * nb + d]; });
+            jac_add(s, acc, r); acc = s;
+        }
+        wsum[w] = acc;
+    }
+    JacP<F> acc = wsum[W - 1];
+    for (int w = W - 2; w >= 0; w--) msm_horner_step(acc, wsum[w], c);
+    AffP<F> a; jac_to_affine(a, acc);
+    st(out, a);
+}
 extern "C" {
 
 void hc_pair(const uint8_t *P, const uint8_t *Q, size_t n, uint8_t *out) {
@@ -324,6 +359,14 @@ void hc_g1_fb_msm(const uint8_t *B, size_t nbase, const uint8_t *K, size_t n_msm
         AffP<Fe> a; jac_to_affine(a, acc);
         fe_store(out + 64 * m, a.x); fe_store(out + 64 * m + 32, a.y);
     }
+}
+void hc_msm(int g2, const uint8_t *B, const uint8_t *K, size_t n, int c, uint8_t *out) {
+    if (!g2) msm_host<Fe>(B, K, n, c, out, 64,
+                          [](const uint8_t *p) { return AffP<Fe>{fe_load(p), fe_load(p + 32), bytes_all_zero(p, 16)}; },
+                          [](uint8_t *p, const AffP<Fe> &r) { fe_store(p, r.x); fe_store(p + 32, r.y); });
+    else msm_host<F2>(B, K, n, c, out, 128,
+                      [](const uint8_t *p) { return AffP<F2>{f2_load(p), f2_load(p + 64), bytes_all_zero(p, 32)}; },
+                      [](uint8_t *p, const AffP<F2> &r) { f2_store(p, r.x); f2_store(p + 64, r.y); });
 }
 // worst-case figures since process start: [max |int64 column|, max limb bound, max value bound (units of p),
 // #products (fe_mul + fe_mul2), #norms, #fe_mul2, #reduces]  (out must hold 7 doubles)

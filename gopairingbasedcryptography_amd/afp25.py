@@ -44,6 +44,8 @@ def quotient_by_root(coeffs, root):
 def commit_g1(engine, g1, tau_powers, coeffs):
     """[p(tau)]_1 = coef_0*g1 + sum_j coef_j*[tau^j]_1  (computeG1PolynomialTau, afp25_bibe_utils.go:45-55)."""
     pts = np.concatenate([np.asarray(g1, dtype=np.uint8).reshape(1, 64), np.asarray(tau_powers, dtype=np.uint8)[: len(coeffs) - 1]])
+    if hasattr(engine, "g1_scalar_mul_sum"):                    # one call: sum_j [c_j] srs_j (the bucket method from 16 384 terms on)
+        return np.asarray(engine.g1_scalar_mul_sum(pts, [int(c) for c in coeffs]))
     return np.asarray(engine.g1_sum(engine.g1_scalar_mul(pts, [int(c) for c in coeffs])))
 
 

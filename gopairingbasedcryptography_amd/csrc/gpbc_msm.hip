@@ -5,9 +5,13 @@
 //   k_msm_count      one lane per term: its W digits -> histogram of the keys (atomics in L2; digit 0 and infinite bases skipped)
 //   k_scan_*         exclusive prefix sum of the histogram (three small kernels)
 //   k_msm_scatter    one lane per term again: term index into its slot of every bucket it belongs to
-//   k_msm_buckets    one lane per bucket: mixed additions of its terms (gathered 64 / 128-byte affine points) -> Jacobian row
-//   k_msm_groups     one lane per (window, 16 digits): running-sum reduction + one multiplication by a 16-bit integer
-//   k_msm_rows_sum   fan-in-64 sums of the group rows of a window (two levels)
+//   k_msm_bases      one lane per term: the base in internal limb form (the Montgomery conversion once, not once per window)
+//   k_size_hist / k_size_scatter   buckets ordered by size (largest first; block-wise counting sort over 256 size classes) so
+//                    that the 64 lanes of a wave run chains of equal length
+//   k_msm_buckets    one lane per bucket: mixed additions of its terms (gathered 80 / 160-byte rows) -> Jacobian row
+//   k_msm_groups     one lane per (window, 8 digits): running-sum reduction + one multiplication by a 16-bit integer
+//   k_msm_rows_sum   fan-in-8 sums of the group rows of a window, level by level (serial chains of 8 additions, not 64:
+//                    these last steps have few lanes and are latency-bound)
 //   k_msm_finish     one lane: Horner over the windows, affine result in gnark's layout
 // All scratch is one stream-ordered allocation; the call is asynchronous on `stream`.
 #include "gpbc_common.hpp"
@@ -86,14 +90,63 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_add(uint32_t *__restrict__ 
     if (blockIdx.x == 0 && threadIdx.x == 0) out[m] = *total;   // sentinel: offsets[m] = number of (term, window) entries
 }
 
-template <class F> __global__ void __launch_bounds__(BLOCK, sizeof(F) == sizeof(Fe) ? GPBC_WAVES_G1 : GPBC_WAVES_PER_SIMD)
-k_msm_buckets(const uint8_t *__restrict__ bases, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ idx, int c, size_t M, int32_t *__restrict__ rows) {
-    size_t key = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (key >= M) return;
+// bases in internal limb form: x, y limbs + infinity flag, 20 (G1) / 40 (G2) dwords per point
+template <class F> struct BaseRow { static constexpr int DWORDS = sizeof(F) == sizeof(Fe) ? 20 : 40; };
+template <class F> __global__ void __launch_bounds__(BLOCK) k_msm_bases(const uint8_t *__restrict__ bases, size_t n, int32_t *__restrict__ rows) {
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
     constexpr size_t PT = sizeof(F) == sizeof(Fe) ? GPBC_G1_BYTES : GPBC_G2_BYTES;
+    constexpr int E = sizeof(F) / sizeof(Fe) * NL;
+    AffP<F> a = base_load<F>(bases + i * PT);
+    int32_t *r = rows + i * BaseRow<F>::DWORDS;
+    limbs_store(r, a.x); limbs_store(r + E, a.y);
+    r[2 * E] = a.inf ? 1 : 0;
+    r[2 * E + 1] = 0;
+}
+template <class F> __device__ __forceinline__ AffP<F> base_row_load(const int32_t *r) {
+    constexpr int E = sizeof(F) / sizeof(Fe) * NL;
+    AffP<F> a;
+    limbs_load(a.x, r); limbs_load(a.y, r + E);
+    a.inf = r[2 * E] != 0;
+    return a;
+}
+
+// Buckets ordered by size, largest first: a block-wise counting sort over 256 size classes (size 255 and more share one).
+// k_size_hist: per block of 256 keys, how many fall into each class, stored class-major (hist[class * n_blocks + block]) so that
+// ONE exclusive scan of that array yields every block's first slot for every class; k_size_scatter: each key takes the next slot
+// of its (class, block) cell.  perm[slot] = key.
+__device__ __forceinline__ uint32_t size_class(const uint32_t *offsets, size_t key, size_t M, int c) {
+    if (key >= M || (key & (((size_t)1 << c) - 1)) == 0) return 255u;          // digit 0 / padding: empty, sorted last
+    const uint32_t cnt = offsets[key + 1] - offsets[key];
+    return 255u - (cnt > 255u ? 255u : cnt);
+}
+__global__ void __launch_bounds__(SCAN_BLOCK) k_size_hist(const uint32_t *__restrict__ offsets, size_t M, int c, uint32_t *__restrict__ hist, size_t n_blocks) {
+    __shared__ uint32_t sh[256];
+    sh[threadIdx.x] = 0;
+    __syncthreads();
+    const size_t key = (size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
+    if (key < M) atomicAdd(&sh[size_class(offsets, key, M, c)], 1u);
+    __syncthreads();
+    hist[(size_t)threadIdx.x * n_blocks + blockIdx.x] = sh[threadIdx.x];
+}
+__global__ void __launch_bounds__(SCAN_BLOCK) k_size_scatter(const uint32_t *__restrict__ offsets, size_t M, int c, const uint32_t *__restrict__ hist_scanned, size_t n_blocks,
+                                                            uint32_t *__restrict__ perm) {
+    __shared__ uint32_t sh[256];
+    sh[threadIdx.x] = hist_scanned[(size_t)threadIdx.x * n_blocks + blockIdx.x];
+    __syncthreads();
+    const size_t key = (size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
+    if (key < M) perm[atomicAdd(&sh[size_class(offsets, key, M, c)], 1u)] = (uint32_t)key;
+}
+
+template <class F> __global__ void __launch_bounds__(BLOCK, sizeof(F) == sizeof(Fe) ? GPBC_WAVES_G1 : GPBC_WAVES_PER_SIMD)
+k_msm_buckets(const int32_t *__restrict__ base_rows, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ perm, int c, size_t M,
+              int32_t *__restrict__ rows) {
+    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= M) return;
+    const size_t key = perm[t];                                              // neighbouring lanes: buckets of (nearly) equal size
     JacP<F> acc;
     if ((key & (((size_t)1 << c) - 1)) == 0) jac_set_inf(acc);               // digit 0 has no bucket
-    else msm_bucket_sum(acc, offsets[key], offsets[key + 1], [&](size_t j) { return base_load<F>(bases + (size_t)idx[j] * PT); });
+    else msm_bucket_sum(acc, offsets[key], offsets[key + 1], [&](size_t j) { return base_row_load<F>(base_rows + (size_t)idx[j] * BaseRow<F>::DWORDS); });
     jac_row_store(rows + key * JacRow<F>::DWORDS, acc);
 }
 template <class F> __global__ void __launch_bounds__(BLOCK, sizeof(F) == sizeof(Fe) ? GPBC_WAVES_G1 : GPBC_WAVES_PER_SIMD)
@@ -135,7 +188,8 @@ template <class F> __global__ void __launch_bounds__(BLOCK) k_msm_finish(const i
     if constexpr (sizeof(F) == sizeof(Fe)) g1_store_aff(out, r); else g2_store_aff(out, r);
 }
 
-struct MsmPlan { int c, W; size_t M, n_groups, rows_l1, bytes; size_t off_counts, off_offsets, off_tiles, off_total, off_idx, off_buckets, off_groups, off_l1, off_l2; };
+constexpr size_t MSM_FAN = 8;
+struct MsmPlan { int c, W; size_t M, n_groups, n_size_blocks, bytes; size_t off_counts, off_offsets, off_tiles, off_total, off_idx, off_buckets, off_groups, off_tmp, off_bases, off_hist, off_hist_scanned, off_perm; };
 static MsmPlan msm_plan(bool g2, size_t n) {
     MsmPlan p;
     p.c = n >= ((size_t)1 << 17) ? 16 : 12;
@@ -143,19 +197,22 @@ static MsmPlan msm_plan(bool g2, size_t n) {
     p.M = (size_t)p.W << p.c;
     p.n_groups = p.M / MSM_GROUP;
     const size_t row = (g2 ? JacRow<F2>::DWORDS : JacRow<Fe>::DWORDS) * sizeof(int32_t);
-    const size_t gpw = ((size_t)1 << p.c) / MSM_GROUP;                 // groups per window: 4096 (c = 16) or 256 (c = 12)
-    p.rows_l1 = (size_t)p.W * (gpw / 64);                              // after one fan-in-64 level: 64 or 4 rows per window
+    const size_t gpw = ((size_t)1 << p.c) / MSM_GROUP;                 // groups per window: 8192 (c = 16) or 512 (c = 12)
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t o = 0;
     p.off_counts = o;  o += up(p.M * 4);
     p.off_offsets = o; o += up((p.M + 1) * 4);
-    p.off_tiles = o;   o += up(((p.M + SCAN_TILE - 1) / SCAN_TILE) * 4);
+    p.off_tiles = o;   o += up((((p.M > 256 * ((p.M + SCAN_BLOCK - 1) / SCAN_BLOCK) ? p.M : 256 * ((p.M + SCAN_BLOCK - 1) / SCAN_BLOCK)) + SCAN_TILE - 1) / SCAN_TILE) * 4);   // tile sums of the larger of the two scans
     p.off_total = o;   o += 256;
     p.off_idx = o;     o += up(n * (size_t)p.W * 4);
     p.off_buckets = o; o += up(p.M * row);
     p.off_groups = o;  o += up(p.n_groups * row);
-    p.off_l1 = o;      o += up(p.rows_l1 * row);
-    p.off_l2 = o;      o += up((size_t)p.W * row);
+    p.off_tmp = o;     o += up((size_t)p.W * (gpw / MSM_FAN) * row);   // the tree's ping-pong partner of the groups array
+    p.n_size_blocks = (p.M + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    p.off_bases = o;   o += up(n * (g2 ? BaseRow<F2>::DWORDS : BaseRow<Fe>::DWORDS) * sizeof(int32_t));
+    p.off_hist = o;    o += up(256 * p.n_size_blocks * 4);
+    p.off_hist_scanned = o; o += up((256 * p.n_size_blocks + 1) * 4);
+    p.off_perm = o;    o += up(p.M * 4);
     p.bytes = o;
     return p;
 }
@@ -168,7 +225,10 @@ template <class F> static int msm_run(const uint8_t *d_bases, const uint8_t *d_s
     HIP_TRY(hipMallocAsync((void **)&mem, p.bytes, st));
     uint32_t *counts = (uint32_t *)(mem + p.off_counts), *offsets = (uint32_t *)(mem + p.off_offsets), *tiles = (uint32_t *)(mem + p.off_tiles);
     uint32_t *total = (uint32_t *)(mem + p.off_total), *idx = (uint32_t *)(mem + p.off_idx);
-    int32_t *buckets = (int32_t *)(mem + p.off_buckets), *groups = (int32_t *)(mem + p.off_groups), *l1 = (int32_t *)(mem + p.off_l1), *l2 = (int32_t *)(mem + p.off_l2);
+    int32_t *buckets = (int32_t *)(mem + p.off_buckets), *groups = (int32_t *)(mem + p.off_groups), *tmp = (int32_t *)(mem + p.off_tmp);
+    int32_t *base_rows = (int32_t *)(mem + p.off_bases);
+    uint32_t *hist = (uint32_t *)(mem + p.off_hist), *hist_scanned = (uint32_t *)(mem + p.off_hist_scanned), *perm = (uint32_t *)(mem + p.off_perm);
+    const size_t hist_len = 256 * p.n_size_blocks, hist_tiles = (hist_len + SCAN_TILE - 1) / SCAN_TILE;
     const size_t n_tiles = (p.M + SCAN_TILE - 1) / SCAN_TILE;
     const size_t gpw = ((size_t)1 << p.c) / MSM_GROUP;
     int rc = GPBC_OK;
@@ -180,11 +240,26 @@ template <class F> static int msm_run(const uint8_t *d_bases, const uint8_t *d_s
     if (rc == GPBC_OK) { k_scan_add<<<(unsigned)n_tiles, SCAN_BLOCK, 0, st>>>(offsets, tiles, p.M, total); step("k_scan_add"); }
     if (rc == GPBC_OK && hipMemsetAsync(counts, 0, p.M * 4, st) != hipSuccess) rc = fail(GPBC_ERR_HIP, "hipMemsetAsync failed");
     if (rc == GPBC_OK) { k_msm_keys<F, true><<<grid_for(n), BLOCK, 0, st>>>(d_bases, d_scalars, n, p.c, p.W, counts, offsets, idx); step(G2 ? "k_msm_scatter_g2" : "k_msm_scatter_g1"); }
-    if (rc == GPBC_OK) { k_msm_buckets<F><<<grid_for(p.M), BLOCK, 0, st>>>(d_bases, offsets, idx, p.c, p.M, buckets); step(G2 ? "k_msm_buckets_g2" : "k_msm_buckets_g1"); }
+    if (rc == GPBC_OK) { k_msm_bases<F><<<grid_for(n), BLOCK, 0, st>>>(d_bases, n, base_rows); step(G2 ? "k_msm_bases_g2" : "k_msm_bases_g1"); }
+    // buckets by size (the tile-sum scratch of the first scan is free again: hist_tiles <= n_tiles of the key scan for c = 16; a
+    // separate region keeps it simple)
+    if (rc == GPBC_OK) { k_size_hist<<<(unsigned)p.n_size_blocks, SCAN_BLOCK, 0, st>>>(offsets, p.M, p.c, hist, p.n_size_blocks); step("k_size_hist"); }
+    if (rc == GPBC_OK) { k_scan_tiles<<<(unsigned)hist_tiles, SCAN_BLOCK, 0, st>>>(hist, hist_scanned, tiles, hist_len); step("k_scan_tiles"); }
+    if (rc == GPBC_OK) { k_scan_tops<<<1, SCAN_BLOCK, 0, st>>>(tiles, hist_tiles, total); step("k_scan_tops"); }
+    if (rc == GPBC_OK) { k_scan_add<<<(unsigned)hist_tiles, SCAN_BLOCK, 0, st>>>(hist_scanned, tiles, hist_len, total); step("k_scan_add"); }
+    if (rc == GPBC_OK) { k_size_scatter<<<(unsigned)p.n_size_blocks, SCAN_BLOCK, 0, st>>>(offsets, p.M, p.c, hist_scanned, p.n_size_blocks, perm); step("k_size_scatter"); }
+    if (rc == GPBC_OK) { k_msm_buckets<F><<<grid_for(p.M), BLOCK, 0, st>>>(base_rows, offsets, idx, perm, p.c, p.M, buckets); step(G2 ? "k_msm_buckets_g2" : "k_msm_buckets_g1"); }
     if (rc == GPBC_OK) { k_msm_groups<F><<<grid_for(p.n_groups), BLOCK, 0, st>>>(buckets, p.c, p.n_groups, groups); step(G2 ? "k_msm_groups_g2" : "k_msm_groups_g1"); }
-    if (rc == GPBC_OK) { k_msm_rows_sum<F><<<grid_for(p.rows_l1), BLOCK, 0, st>>>(groups, p.rows_l1, 64, l1); step(G2 ? "k_msm_rows_sum_g2" : "k_msm_rows_sum_g1"); }
-    if (rc == GPBC_OK) { k_msm_rows_sum<F><<<grid_for((size_t)p.W), BLOCK, 0, st>>>(l1, (size_t)p.W, gpw / 64, l2); step(G2 ? "k_msm_rows_sum_g2" : "k_msm_rows_sum_g1"); }
-    if (rc == GPBC_OK) { k_msm_finish<F><<<1, BLOCK, 0, st>>>(l2, p.c, p.W, d_out); step(G2 ? "k_msm_finish_g2" : "k_msm_finish_g1"); }
+    // tree over the groups of every window: rows are window-major, so segments of `fan` consecutive rows never cross a window
+    int32_t *src = groups, *dst = tmp;
+    for (size_t per_window = gpw; rc == GPBC_OK && per_window > 1;) {
+        const size_t fan = per_window >= MSM_FAN ? MSM_FAN : per_window, next = per_window / fan;
+        k_msm_rows_sum<F><<<grid_for((size_t)p.W * next), BLOCK, 0, st>>>(src, (size_t)p.W * next, fan, dst);
+        step(G2 ? "k_msm_rows_sum_g2" : "k_msm_rows_sum_g1");
+        int32_t *t = src; src = dst; dst = t;
+        per_window = next;
+    }
+    if (rc == GPBC_OK) { k_msm_finish<F><<<1, BLOCK, 0, st>>>(src, p.c, p.W, d_out); step(G2 ? "k_msm_finish_g2" : "k_msm_finish_g1"); }
     (void)hipFreeAsync(mem, st);
     return rc;
 }

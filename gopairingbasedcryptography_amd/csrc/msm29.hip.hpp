@@ -18,7 +18,7 @@
 
 namespace gpbc {
 
-constexpr int MSM_GROUP = 16;                    // digits per group of step 3
+constexpr int MSM_GROUP = 8;                     // digits per group of step 3 (2^c / 8 lanes per window: a full round of the chip at c = 16)
 
 // digit w (c bits, c <= 16) of a 256-bit little-endian scalar held as eight 32-bit words
 GPBC_INLINE uint32_t msm_digit(const uint32_t (&k)[8], int w, int c) {

@@ -26,11 +26,9 @@ template <class F> __device__ __forceinline__ AffP<F> base_load(const uint8_t *p
     if constexpr (sizeof(F) == sizeof(Fe)) return g1_load_aff(p); else return g2_load_aff(p);
 }
 
-// SCATTER = false: histogram pass — the rank the atomic hands back (this term's position inside its bucket) is kept in
-// ranks[i * W + w], so that the second pass (SCATTER = true) places the term index without touching the counters again.
 template <class F, bool SCATTER>
 __global__ void __launch_bounds__(BLOCK) k_msm_keys(const uint8_t *__restrict__ bases, const uint8_t *__restrict__ scalars, size_t n, int c, int W,
-                                                   uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets, uint32_t *__restrict__ idx, uint32_t *__restrict__ ranks) {
+                                                   uint32_t *__restrict__ counts, const uint32_t *__restrict__ offsets, uint32_t *__restrict__ idx) {
     size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     constexpr size_t PT = sizeof(F) == sizeof(Fe) ? GPBC_G1_BYTES : GPBC_G2_BYTES;
@@ -41,8 +39,8 @@ __global__ void __launch_bounds__(BLOCK) k_msm_keys(const uint8_t *__restrict__ 
         const uint32_t d = msm_digit(k, w, c);
         if (!d) continue;
         const uint32_t key = ((uint32_t)w << c) | d;
-        if (SCATTER) idx[offsets[key] + ranks[i * (size_t)W + w]] = (uint32_t)i;
-        else ranks[i * (size_t)W + w] = atomicAdd(&counts[key], 1u);
+        const uint32_t pos = atomicAdd(&counts[key], 1u);
+        if (SCATTER) idx[offsets[key] + pos] = (uint32_t)i;
     }
 }
 
@@ -191,7 +189,7 @@ template <class F> __global__ void __launch_bounds__(BLOCK) k_msm_finish(const i
 }
 
 constexpr size_t MSM_FAN = 8;
-struct MsmPlan { int c, W; size_t M, n_groups, n_size_blocks, bytes, off_ranks; size_t off_counts, off_offsets, off_tiles, off_total, off_idx, off_buckets, off_groups, off_tmp, off_bases, off_hist, off_hist_scanned, off_perm; };
+struct MsmPlan { int c, W; size_t M, n_groups, n_size_blocks, bytes; size_t off_counts, off_offsets, off_tiles, off_total, off_idx, off_buckets, off_groups, off_tmp, off_bases, off_hist, off_hist_scanned, off_perm; };
 static MsmPlan msm_plan(bool g2, size_t n) {
     MsmPlan p;
     p.c = n >= ((size_t)1 << 17) ? 16 : 12;
@@ -207,7 +205,6 @@ static MsmPlan msm_plan(bool g2, size_t n) {
     p.off_tiles = o;   o += up((((p.M > 256 * ((p.M + SCAN_BLOCK - 1) / SCAN_BLOCK) ? p.M : 256 * ((p.M + SCAN_BLOCK - 1) / SCAN_BLOCK)) + SCAN_TILE - 1) / SCAN_TILE) * 4);   // tile sums of the larger of the two scans
     p.off_total = o;   o += 256;
     p.off_idx = o;     o += up(n * (size_t)p.W * 4);
-    p.off_ranks = o;   o += up(n * (size_t)p.W * 4);
     p.off_buckets = o; o += up(p.M * row);
     p.off_groups = o;  o += up(p.n_groups * row);
     p.off_tmp = o;     o += up((size_t)p.W * (gpw / MSM_FAN) * row);   // the tree's ping-pong partner of the groups array
@@ -227,7 +224,7 @@ template <class F> static int msm_run(const uint8_t *d_bases, const uint8_t *d_s
     uint8_t *mem = nullptr;
     HIP_TRY(hipMallocAsync((void **)&mem, p.bytes, st));
     uint32_t *counts = (uint32_t *)(mem + p.off_counts), *offsets = (uint32_t *)(mem + p.off_offsets), *tiles = (uint32_t *)(mem + p.off_tiles);
-    uint32_t *total = (uint32_t *)(mem + p.off_total), *idx = (uint32_t *)(mem + p.off_idx), *ranks = (uint32_t *)(mem + p.off_ranks);
+    uint32_t *total = (uint32_t *)(mem + p.off_total), *idx = (uint32_t *)(mem + p.off_idx);
     int32_t *buckets = (int32_t *)(mem + p.off_buckets), *groups = (int32_t *)(mem + p.off_groups), *tmp = (int32_t *)(mem + p.off_tmp);
     int32_t *base_rows = (int32_t *)(mem + p.off_bases);
     uint32_t *hist = (uint32_t *)(mem + p.off_hist), *hist_scanned = (uint32_t *)(mem + p.off_hist_scanned), *perm = (uint32_t *)(mem + p.off_perm);
@@ -237,11 +234,12 @@ template <class F> static int msm_run(const uint8_t *d_bases, const uint8_t *d_s
     int rc = GPBC_OK;
     auto step = [&](const char *name) { if (rc == GPBC_OK) { rc = check_launch(name); profile_mark(name, st); } };
     if (hipMemsetAsync(counts, 0, p.M * 4, st) != hipSuccess) rc = fail(GPBC_ERR_HIP, "hipMemsetAsync failed");
-    if (rc == GPBC_OK) { k_msm_keys<F, false><<<grid_for(n), BLOCK, 0, st>>>(d_bases, d_scalars, n, p.c, p.W, counts, nullptr, nullptr, ranks); step(G2 ? "k_msm_count_g2" : "k_msm_count_g1"); }
+    if (rc == GPBC_OK) { k_msm_keys<F, false><<<grid_for(n), BLOCK, 0, st>>>(d_bases, d_scalars, n, p.c, p.W, counts, nullptr, nullptr); step(G2 ? "k_msm_count_g2" : "k_msm_count_g1"); }
     if (rc == GPBC_OK) { k_scan_tiles<<<(unsigned)n_tiles, SCAN_BLOCK, 0, st>>>(counts, offsets, tiles, p.M); step("k_scan_tiles"); }
     if (rc == GPBC_OK) { k_scan_tops<<<1, SCAN_BLOCK, 0, st>>>(tiles, n_tiles, total); step("k_scan_tops"); }
     if (rc == GPBC_OK) { k_scan_add<<<(unsigned)n_tiles, SCAN_BLOCK, 0, st>>>(offsets, tiles, p.M, total); step("k_scan_add"); }
-    if (rc == GPBC_OK) { k_msm_keys<F, true><<<grid_for(n), BLOCK, 0, st>>>(d_bases, d_scalars, n, p.c, p.W, counts, offsets, idx, ranks); step(G2 ? "k_msm_scatter_g2" : "k_msm_scatter_g1"); }
+    if (rc == GPBC_OK && hipMemsetAsync(counts, 0, p.M * 4, st) != hipSuccess) rc = fail(GPBC_ERR_HIP, "hipMemsetAsync failed");
+    if (rc == GPBC_OK) { k_msm_keys<F, true><<<grid_for(n), BLOCK, 0, st>>>(d_bases, d_scalars, n, p.c, p.W, counts, offsets, idx); step(G2 ? "k_msm_scatter_g2" : "k_msm_scatter_g1"); }
     if (rc == GPBC_OK) { k_msm_bases<F><<<grid_for(n), BLOCK, 0, st>>>(d_bases, n, base_rows); step(G2 ? "k_msm_bases_g2" : "k_msm_bases_g1"); }
     // buckets by size (the tile-sum scratch of the first scan is free again: hist_tiles <= n_tiles of the key scan for c = 16; a
     // separate region keeps it simple)

@@ -165,6 +165,35 @@ constexpr size_t LINE_BYTES_PER_PAIR = (size_t)88 * 54 * sizeof(int32_t);
 std::mutex &ws_seq_mutex();                                             // of the calling thread's current device
 #define g_ws_seq_mu (ws_seq_mutex())
 int stream_workspace(hipStream_t stream, size_t bytes, int32_t **out);
+// Per-call temporaries of the device-pointer entries (chunk tables and values of the multi-pairings, the fixed-Q line table, the
+// MSM's keys / buckets / rows, the fixed-base window table): a second family of grow-only buffers per (device, stream) and
+// nesting level — level 0 for a routine that calls no other scratch user, level 1 for its caller (scalar_mul_sum_dev around
+// msm_dev).  A repeated call pays no hipMalloc / hipFree, which for the gigabytes of a BASELINE-size BSW07 decrypt were tens of
+// milliseconds per call.  (hipMallocAsync pools were measured instead and dropped: a small host-to-device table copy into a
+// block the pool had just recycled was not seen by the next kernel on the null stream — profiles/r02_pool_bisect.txt.)
+// open() takes the device's scratch lock, which the object holds until it goes out of scope; like the workspace lock it only
+// has to cover the ENQUEUE of the kernels that use the buffer, later calls on the same stream are ordered behind them.
+// Lock order: scratch before workspace.
+std::recursive_mutex &scratch_mutex();                                  // of the calling thread's current device
+int stream_scratch(hipStream_t stream, int level, size_t bytes, void **out);
+struct Scratch {
+    std::unique_lock<std::recursive_mutex> lock;
+    uint8_t *base = nullptr;
+    size_t off = 0, cap = 0;
+    static size_t padded(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+    int open(hipStream_t stream, int level, size_t bytes) {
+        lock = std::unique_lock<std::recursive_mutex>(scratch_mutex());
+        void *p = nullptr;
+        TRY(stream_scratch(stream, level, bytes ? bytes : 256, &p));
+        base = (uint8_t *)p; off = 0; cap = bytes;
+        return GPBC_OK;
+    }
+    template <class T = uint8_t> T *take(size_t bytes) {            // the next 256-byte aligned piece (sizes summed with padded())
+        T *p = (T *)(base + off);
+        off += padded(bytes);
+        return p;
+    }
+};
 static inline int lines_workspace(hipStream_t stream, size_t pairs, int32_t **out) { return stream_workspace(stream, pairs * LINE_BYTES_PER_PAIR, out); }
 void free_workspaces();
 

@@ -24,6 +24,7 @@ constexpr int MAX_DEVICES = 64;
 struct DeviceCtx {
     int hip = -1;                 // HIP ordinal
     std::mutex ws_seq;            // held while a call enqueues kernels that share this device's stream workspace
+    std::recursive_mutex scratch; // held while a call enqueues kernels that use this device's stream scratch (gpbc_common.hpp)
     ncclComm_t comm = nullptr;    // RCCL communicator of this device (rank = comm_rank of comm_ranks), or null
     hipStream_t pipe[3] = {nullptr, nullptr, nullptr};   // large host-pointer calls: two compute streams + one download stream
     std::mutex pipe_mu;
@@ -52,6 +53,10 @@ int bind_device() {
 std::mutex &ws_seq_mutex() {
     int n = g_ndev.load(), i = cur_index();
     return g_ctx[(n > 0 && i < n) ? i : 0].ws_seq;
+}
+std::recursive_mutex &scratch_mutex() {
+    int n = g_ndev.load(), i = cur_index();
+    return g_ctx[(n > 0 && i < n) ? i : 0].scratch;
 }
 // Three non-blocking streams per bound device slot, created on first use: a large host-pointer call cuts its batch into
 // chunks, alternates them on the first two and drains results on the third (gpbc_common.hpp: pipelined_chunks).
@@ -115,14 +120,14 @@ int run_sharded(size_t n, size_t min_units, const std::function<int(size_t, size
 }
 
 // ---- internal workspace, one grow-only buffer per (bound device slot, stream)
-struct StreamWs { int device; hipStream_t stream; void *ptr; size_t bytes; };      // device = index into g_ctx
+struct StreamWs { int device; hipStream_t stream; int kind; void *ptr; size_t bytes; };      // device = index into g_ctx; kind 0 = workspace, 1 + level = scratch
 static std::mutex g_ws_mu;
 static std::vector<StreamWs> g_ws;
-int stream_workspace(hipStream_t stream, size_t bytes, int32_t **out) {
+static int stream_buffer(int kind, hipStream_t stream, size_t bytes, void **out) {
     int dev = cur_index();
     std::lock_guard<std::mutex> lk(g_ws_mu);
     for (auto &w : g_ws)
-        if (w.device == dev && w.stream == stream) {
+        if (w.device == dev && w.stream == stream && w.kind == kind) {
             if (w.bytes < bytes) {
                 HIP_TRY(hipStreamSynchronize(stream));
                 HIP_TRY(hipFree(w.ptr));
@@ -130,15 +135,17 @@ int stream_workspace(hipStream_t stream, size_t bytes, int32_t **out) {
                 HIP_TRY(hipMalloc(&w.ptr, bytes));
                 w.bytes = bytes;
             }
-            *out = (int32_t *)w.ptr;
+            *out = w.ptr;
             return GPBC_OK;
         }
     void *ptr = nullptr;
     HIP_TRY(hipMalloc(&ptr, bytes));
-    g_ws.push_back(StreamWs{dev, stream, ptr, bytes});
-    *out = (int32_t *)ptr;
+    g_ws.push_back(StreamWs{dev, stream, kind, ptr, bytes});
+    *out = ptr;
     return GPBC_OK;
 }
+int stream_workspace(hipStream_t stream, size_t bytes, int32_t **out) { return stream_buffer(0, stream, bytes, (void **)out); }
+int stream_scratch(hipStream_t stream, int level, size_t bytes, void **out) { return stream_buffer(1 + level, stream, bytes, out); }
 void free_workspaces() {
     std::lock_guard<std::mutex> lk(g_ws_mu);
     for (auto &w : g_ws) if (w.ptr) { if (g_ctx[w.device].hip >= 0) (void)hipSetDevice(g_ctx[w.device].hip); (void)hipFree(w.ptr); }

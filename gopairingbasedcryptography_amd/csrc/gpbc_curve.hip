@@ -143,10 +143,10 @@ constexpr size_t FB_AUTO_MIN = 16384;
 static int shared_base_mul_dev(bool g2, const void *d_base, const void *d_scalars, size_t n, void *d_out, hipStream_t st) {
     const size_t row_dwords = g2 ? (size_t)TabLayout<F2>::ENTRY_DWORDS : (size_t)TabLayout<Fe>::ENTRY_DWORDS;
     const size_t table_bytes = (size_t)FB_ENTRIES * row_dwords * sizeof(int32_t);
-    void *mem = nullptr;
-    if (hipMallocAsync(&mem, table_bytes + 256, st) != hipSuccess) { (void)hipGetLastError(); return GPBC_ERR_WORKSPACE; }
-    int32_t *table = (int32_t *)mem;
-    uint8_t *base_inf = (uint8_t *)mem + table_bytes;
+    Scratch tmp;
+    if (tmp.open(st, 0, Scratch::padded(table_bytes) + 256) != GPBC_OK) return GPBC_ERR_WORKSPACE;
+    int32_t *table = tmp.take<int32_t>(table_bytes);
+    uint8_t *base_inf = tmp.take(256);
     const size_t tab_bytes = sizeof(int32_t) * (g2 ? (size_t)glv_table_dwords<F2>() : (size_t)glv_table_dwords<Fe>());
     int rc;
     {
@@ -166,7 +166,6 @@ static int shared_base_mul_dev(bool g2, const void *d_base, const void *d_scalar
         rc = check_launch("k_fb_msm");
         profile_mark(g2 ? "k_g2_fb_msm" : "k_g1_fb_msm", st);
     }
-    (void)hipFreeAsync(mem, st);                                     // stream-ordered: released after the kernels above
     return rc;
 }
 static int scalar_mul_dev(bool g2, const void *d_bases, size_t nbase, const void *d_scalars, size_t n, void *d_out, void *stream) {
@@ -389,8 +388,9 @@ static int scalar_mul_sum_dev(bool g2, const void *d_bases, const void *d_scalar
     const size_t wsb_local = bucket ? 0 : gpbc_sum_workspace_bytes(n, g2), wsb_all = gpbc_sum_workspace_bytes((size_t)(ranks > 1 ? ranks : 1), g2);
     // one stream-ordered scratch block: products | local tree workspace | local sum | gathered sums | final tree workspace
     const size_t total = (bucket ? 0 : n * pt) + wsb_local + pt + (size_t)(ranks > 1 ? ranks : 1) * pt + wsb_all;
-    uint8_t *mem = nullptr;
-    HIP_TRY(hipMallocAsync((void **)&mem, total, st));
+    Scratch tmp;                                                   // level 1: msm_dev and the shared-base path use level 0 underneath
+    TRY(tmp.open(st, 1, total));
+    uint8_t *mem = tmp.base;
     uint8_t *prod = mem, *ws1 = prod + (bucket ? 0 : n * pt), *local = ws1 + wsb_local, *all = local + pt, *ws2 = all + (size_t)(ranks > 1 ? ranks : 1) * pt;
     int rc = GPBC_OK;
     uint8_t *local_out = ranks > 1 ? local : (uint8_t *)d_out;
@@ -403,7 +403,6 @@ static int scalar_mul_sum_dev(bool g2, const void *d_bases, const void *d_scalar
         rc = comm_allgather(local, pt, all, st);
         if (rc == GPBC_OK) rc = sum_dev(g2, all, (size_t)ranks, d_out, ws2, wsb_all, stream);
     }
-    (void)hipFreeAsync(mem, st);
     return rc;
 }
 int gpbc_g1_scalar_mul_sum_dev(const void *b, const void *s, size_t n, void *o, void *st) { return scalar_mul_sum_dev(false, b, s, n, o, st); }

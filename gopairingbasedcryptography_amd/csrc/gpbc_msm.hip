@@ -221,8 +221,9 @@ template <class F> static int msm_run(const uint8_t *d_bases, const uint8_t *d_s
     constexpr bool G2 = sizeof(F) != sizeof(Fe);
     const MsmPlan p = msm_plan(G2, n);
     if (n * (size_t)p.W >= ((size_t)1 << 32)) return fail(GPBC_ERR_INVALID_ARG, "MSM of %zu terms exceeds the 32-bit index space of one call", n);
-    uint8_t *mem = nullptr;
-    HIP_TRY(hipMallocAsync((void **)&mem, p.bytes, st));
+    Scratch scratch;
+    TRY(scratch.open(st, 0, p.bytes));
+    uint8_t *mem = scratch.base;
     uint32_t *counts = (uint32_t *)(mem + p.off_counts), *offsets = (uint32_t *)(mem + p.off_offsets), *tiles = (uint32_t *)(mem + p.off_tiles);
     uint32_t *total = (uint32_t *)(mem + p.off_total), *idx = (uint32_t *)(mem + p.off_idx);
     int32_t *buckets = (int32_t *)(mem + p.off_buckets), *groups = (int32_t *)(mem + p.off_groups), *tmp = (int32_t *)(mem + p.off_tmp);
@@ -260,7 +261,6 @@ template <class F> static int msm_run(const uint8_t *d_bases, const uint8_t *d_s
         per_window = next;
     }
     if (rc == GPBC_OK) { k_msm_finish<F><<<1, BLOCK, 0, st>>>(src, p.c, p.W, d_out); step(G2 ? "k_msm_finish_g2" : "k_msm_finish_g1"); }
-    (void)hipFreeAsync(mem, st);
     return rc;
 }
 

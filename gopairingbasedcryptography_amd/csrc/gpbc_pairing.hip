@@ -137,10 +137,13 @@ GPBC_KERNEL k_miller_accumulate_fixed_q(const int32_t *__restrict__ Pint, const 
         const size_t i = (size_t)vi[p];
         LineS r = line_load(qlines, m, i, li);                    // raw (r0, r1, r2) of Q_i: the same address for the whole wave
         const int32_t *pp = Pint + (j * m + i) * 20;
-        Fe px, py;
+        // the line at P: c0 = r0 * yP, c3 = r1 * xP.  Both lanes of the pair need both; each computes ONE of the two Fp x Fp2
+        // products (even lane c0, odd lane c3) and they swap — half the evaluation work of computing both on both lanes
+        Fe pc;
 #pragma unroll
-        for (int w = 0; w < NL; w++) { px.v[w] = pp[w]; py.v[w] = pp[NL + w]; }
-        return LineS{f2_mul_fe(r.c0, py), f2_mul_fe(r.c3, px), r.c4};
+        for (int w = 0; w < NL; w++) pc.v[w] = x.odd ? pp[w] : pp[NL + w];            // odd: xP, even: yP
+        const F2 mine = f2_mul_fe(f2_sel(x.odd, r.c3, r.c0), pc), other = x.swap(mine);
+        return LineS{f2_sel(x.odd, other, mine), f2_sel(x.odd, mine, other), r.c4};
     });
     f6_store(f_out + (j * n_c + c) * GPBC_GT_BYTES + (x.odd ? 192 : 0), h);     // segment-major: chunks of a segment are adjacent
 }
@@ -166,6 +169,18 @@ GPBC_KERNEL k_segment_product(const uint8_t *__restrict__ f, const uint64_t *__r
     if (hi > n_pairs) hi = n_pairs;
     if (lo > hi) lo = hi;
     for (uint64_t i = lo; i < hi; i++) {
+        f12_load(t, f + i * GPBC_GT_BYTES);
+        acc = f12_mul(acc, t);
+    }
+    f12_store(out + j * GPBC_GT_BYTES, acc);
+}
+
+// the same product over equal runs of n_c values per output (fixed-Q multi-pairing: no table needed)
+GPBC_KERNEL k_chunk_product(const uint8_t *__restrict__ f, uint8_t *__restrict__ out, size_t k, size_t n_c) {
+    size_t j = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= k) return;
+    F12 acc = f12_one(), t;
+    for (size_t i = j * n_c; i < (j + 1) * n_c; i++) {
         f12_load(t, f + i * GPBC_GT_BYTES);
         acc = f12_mul(acc, t);
     }
@@ -424,15 +439,19 @@ static int multi_pair_core(const uint8_t *dP, const uint8_t *dQ, const uint64_t 
     if (g_multi_chunk.load() > 0) L = (uint64_t)g_multi_chunk.load();
     if (L <= 1 && g_multi_chunk.load() <= 0) {
         // nothing to share (few pairs, or single-pair segments): one Miller loop per lane pair and one product per segment
-        DevBuf dSeg, dW;
-        TRY(dSeg.upload(seg_off, (k + 1) * sizeof(uint64_t)));
-        const size_t wsb = gpbc_multi_pair_workspace_bytes(n_pairs, k);
-        TRY(dW.alloc(wsb));
-        TRY(gpbc_multi_pair_dev(dP, dQ, (const uint64_t *)dSeg.p, n_pairs, k, dG, dW.p, wsb, st));
-        if (dOk) {
-            k_gt_is_one<<<grid_for(k), BLOCK, 0, st>>>(dG, dOk, k);
-            TRY(check_launch("k_gt_is_one"));
-            profile_mark("k_gt_is_one", st);
+        {
+            const size_t wsb = gpbc_multi_pair_workspace_bytes(n_pairs, k), seg_bytes = (k + 1) * sizeof(uint64_t);
+            Scratch tmp;
+            TRY(tmp.open(st, 0, Scratch::padded(seg_bytes) + Scratch::padded(wsb)));
+            uint64_t *dSeg = tmp.take<uint64_t>(seg_bytes);
+            uint8_t *dW = tmp.take(wsb);
+            HIP_TRY(hipMemcpyAsync(dSeg, seg_off, seg_bytes, hipMemcpyHostToDevice, st));
+            TRY(gpbc_multi_pair_dev(dP, dQ, dSeg, n_pairs, k, dG, dW, wsb, st));
+            if (dOk) {
+                k_gt_is_one<<<grid_for(k), BLOCK, 0, st>>>(dG, dOk, k);
+                TRY(check_launch("k_gt_is_one"));
+                profile_mark("k_gt_is_one", st);
+            }
         }
         HIP_TRY(hipStreamSynchronize(st));
         return GPBC_OK;
@@ -446,11 +465,14 @@ static int multi_pair_core(const uint8_t *dP, const uint8_t *dQ, const uint64_t 
         seg_chunk.push_back(chunk_off.size() - 1);
     }
     const size_t n_chunks = chunk_off.size() - 1;
-    DevBuf dChunkOff, dSegChunk, dPart;
-    TRY(dChunkOff.upload(chunk_off.data(), chunk_off.size() * sizeof(uint64_t)));
-    TRY(dSegChunk.upload(seg_chunk.data(), seg_chunk.size() * sizeof(uint64_t)));
-    TRY(dPart.alloc(n_chunks * GPBC_GT_BYTES));
     {
+        const size_t co_bytes = chunk_off.size() * sizeof(uint64_t), sc_bytes = seg_chunk.size() * sizeof(uint64_t);
+        Scratch tmp;
+        TRY(tmp.open(st, 0, Scratch::padded(co_bytes) + Scratch::padded(sc_bytes) + Scratch::padded(n_chunks * GPBC_GT_BYTES)));
+        uint64_t *dChunkOff = tmp.take<uint64_t>(co_bytes), *dSegChunk = tmp.take<uint64_t>(sc_bytes);
+        uint8_t *dPart = tmp.take(n_chunks * GPBC_GT_BYTES);
+        HIP_TRY(hipMemcpyAsync(dChunkOff, chunk_off.data(), co_bytes, hipMemcpyHostToDevice, st));   // the vectors outlive the
+        HIP_TRY(hipMemcpyAsync(dSegChunk, seg_chunk.data(), sc_bytes, hipMemcpyHostToDevice, st));   // synchronisation below
         std::lock_guard<std::mutex> seq(g_ws_seq_mu);
         for (size_t cb = 0; cb < n_chunks; cb += MULTI_GROUP) {
             const size_t g = n_chunks - cb < MULTI_GROUP ? n_chunks - cb : MULTI_GROUP;
@@ -459,18 +481,18 @@ static int multi_pair_core(const uint8_t *dP, const uint8_t *dQ, const uint64_t 
             const size_t n_slots = longest * g;
             int32_t *lines = nullptr;
             TRY(lines_workspace(st, n_slots, &lines));
-            const uint64_t *co = (const uint64_t *)dChunkOff.p + cb;
+            const uint64_t *co = dChunkOff + cb;
             k_miller_lines_chunks<<<grid_for(n_slots), BLOCK, 0, st>>>(dP, dQ, lines, co, g, n_slots);
             TRY(check_launch("k_miller_lines_chunks"));
             profile_mark("k_miller_lines_chunks", st);
-            k_miller_accumulate_chunks<<<grid_for(2 * g), BLOCK, 0, st>>>(dP, dQ, lines, co, dPart.u8() + cb * GPBC_GT_BYTES, g, n_slots);
+            k_miller_accumulate_chunks<<<grid_for(2 * g), BLOCK, 0, st>>>(dP, dQ, lines, co, dPart + cb * GPBC_GT_BYTES, g, n_slots);
             TRY(check_launch("k_miller_accumulate_chunks"));
             profile_mark("k_miller_accumulate_chunks", st);
         }
+        k_segment_product<<<grid_for(k), BLOCK, 0, st>>>(dPart, dSegChunk, dG, k, n_chunks);
+        TRY(check_launch("k_segment_product (segments)"));
+        profile_mark("k_segment_product", st);
     }
-    k_segment_product<<<grid_for(k), BLOCK, 0, st>>>(dPart.u8(), (const uint64_t *)dSegChunk.p, dG, k, n_chunks);
-    TRY(check_launch("k_segment_product (segments)"));
-    profile_mark("k_segment_product", st);
     TRY(gpbc_final_exp_dev(dG, k, dG, st));
     if (dOk) {
         k_gt_is_one<<<grid_for(k), BLOCK, 0, st>>>(dG, dOk, k);
@@ -480,7 +502,7 @@ static int multi_pair_core(const uint8_t *dP, const uint8_t *dQ, const uint64_t 
     HIP_TRY(hipStreamSynchronize(st));
     return GPBC_OK;
 }
-// out[j] = Pair(P[j*m .. (j+1)*m), Q[0 .. m)), j < k.  Synchronises the stream before returning.
+// out[j] = Pair(P[j*m .. (j+1)*m), Q[0 .. m)), j < k.  Asynchronous on the stream (its temporaries live in the stream's scratch).
 int gpbc_multi_pair_fixed_q_dev(const void *dP, const void *dQ, size_t m, size_t k, void *d_gt_out, void *stream) {
     if (!k || !m) return fail(GPBC_ERR_INVALID_ARG, "invalid inputs sizes");
     if (!dP || !dQ || !d_gt_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
@@ -493,28 +515,26 @@ int gpbc_multi_pair_fixed_q_dev(const void *dP, const void *dQ, size_t m, size_t
     if (L > (size_t)MULTI_CHUNK) L = MULTI_CHUNK;
     if (L > m) L = m;
     const size_t n_c = (m + L - 1) / L;
-    DevBuf dLines, dPint, dPart, dSegChunk;
-    TRY(dLines.alloc(m * LINE_BYTES_PER_PAIR));
-    TRY(dPint.alloc(m * k * 20 * sizeof(int32_t)));
-    TRY(dPart.alloc(n_c * k * GPBC_GT_BYTES));
-    std::vector<uint64_t> seg_chunk(k + 1);
-    for (size_t j = 0; j <= k; j++) seg_chunk[j] = j * n_c;
-    TRY(dSegChunk.upload(seg_chunk.data(), seg_chunk.size() * sizeof(uint64_t)));
-    k_q_lines<<<grid_for(m), BLOCK, 0, st>>>((const uint8_t *)dQ, (int32_t *)dLines.p, m);
-    TRY(check_launch("k_q_lines"));
-    profile_mark("k_q_lines", st);
-    k_g1_internal<<<grid_for(m * k), BLOCK, 0, st>>>((const uint8_t *)dP, (int32_t *)dPint.p, m * k);
-    TRY(check_launch("k_g1_internal"));
-    profile_mark("k_g1_internal", st);
-    k_miller_accumulate_fixed_q<<<grid_for(2 * n_c * k), BLOCK, 0, st>>>((const int32_t *)dPint.p, (const uint8_t *)dQ, (const int32_t *)dLines.p, dPart.u8(), m, k, L, n_c);
-    TRY(check_launch("k_miller_accumulate_fixed_q"));
-    profile_mark("k_miller_accumulate_fixed_q", st);
-    k_segment_product<<<grid_for(k), BLOCK, 0, st>>>(dPart.u8(), (const uint64_t *)dSegChunk.p, (uint8_t *)d_gt_out, k, n_c * k);
-    TRY(check_launch("k_segment_product"));
-    profile_mark("k_segment_product", st);
-    TRY(gpbc_final_exp_dev(d_gt_out, k, d_gt_out, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    return GPBC_OK;
+    {
+        const size_t pint_bytes = m * k * 20 * sizeof(int32_t), part_bytes = n_c * k * GPBC_GT_BYTES;
+        Scratch tmp;
+        TRY(tmp.open(st, 0, Scratch::padded(m * LINE_BYTES_PER_PAIR) + Scratch::padded(pint_bytes) + Scratch::padded(part_bytes)));
+        int32_t *dLines = tmp.take<int32_t>(m * LINE_BYTES_PER_PAIR), *dPint = tmp.take<int32_t>(pint_bytes);
+        uint8_t *dPart = tmp.take(part_bytes);
+        k_q_lines<<<grid_for(m), BLOCK, 0, st>>>((const uint8_t *)dQ, dLines, m);
+        TRY(check_launch("k_q_lines"));
+        profile_mark("k_q_lines", st);
+        k_g1_internal<<<grid_for(m * k), BLOCK, 0, st>>>((const uint8_t *)dP, dPint, m * k);
+        TRY(check_launch("k_g1_internal"));
+        profile_mark("k_g1_internal", st);
+        k_miller_accumulate_fixed_q<<<grid_for(2 * n_c * k), BLOCK, 0, st>>>(dPint, (const uint8_t *)dQ, dLines, dPart, m, k, L, n_c);
+        TRY(check_launch("k_miller_accumulate_fixed_q"));
+        profile_mark("k_miller_accumulate_fixed_q", st);
+        k_chunk_product<<<grid_for(k), BLOCK, 0, st>>>(dPart, (uint8_t *)d_gt_out, k, n_c);      // ciphertext j owns chunk values [j n_c, (j+1) n_c)
+        TRY(check_launch("k_chunk_product"));
+        profile_mark("k_chunk_product", st);
+    }
+    return gpbc_final_exp_dev(d_gt_out, k, d_gt_out, st);
 }
 static int multi_pair_fixed_q_one(const void *P, const void *Q, size_t m, size_t k, void *gt_out) {
     TRY(bind_device());

@@ -121,7 +121,8 @@ int gpbc_multi_pair_hostseg_dev(const void *dP, const void *dQ, const uint64_t *
  * ciphertexts (access/tree/access_tree_node.go:106-119 under cpabe/bsw07/bsw07_cpabe.go:172-195: the D_j of a key are the
  * same for every ciphertext), one public key against k signatures.  The line coefficients of each Q_i are computed once
  * and reused by all k segments (gnark: PrecomputeLines / MillerLoopFixedQ), on top of the shared squarings; results are
- * bit-identical to gpbc_multi_pair on the replicated list.  P: k*m points, segment-major.  Synchronises `stream`. */
+ * bit-identical to gpbc_multi_pair on the replicated list.  P: k*m points, segment-major.  The _dev form is asynchronous on
+ * `stream`; its temporaries (line table, converted points, chunk values) stay in a per-stream scratch buffer between calls. */
 int gpbc_multi_pair_fixed_q(const void *P, const void *Q, size_t m, size_t k, void *gt_out);
 int gpbc_multi_pair_fixed_q_dev(const void *dP, const void *dQ, size_t m, size_t k, void *d_gt_out, void *stream);
 /* Tuning / test knob of that path: pairs per shared-squaring chunk, 1..8; 0 (default) = chosen from the batch size. */

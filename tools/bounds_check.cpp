@@ -248,7 +248,8 @@ void hc_pair_fixed_q(const uint8_t *P, const uint8_t *Q, size_t n, uint8_t *out,
         PairHost x{odd, &rv};
         F6 h = miller_accumulate_multi(x, (int)n, [&](int p, int li) -> LineS {
             const LineE &r = raw[(size_t)p * MILLER_LINES + li];
-            return LineS{f2_mul_fe(r.r0, pts[p].y), f2_mul_fe(r.r1, pts[p].x), r.r2};
+            const F2 mine = f2_mul_fe(x.odd ? r.r1 : r.r0, x.odd ? pts[p].x : pts[p].y), other = x.swap(mine);   // one product per lane, swapped
+            return LineS{x.odd ? other : mine, x.odd ? mine : other, r.r2};
         });
         if (do_final_exp) h = final_exp_pair(x, h);
         f6_store(out + (odd ? 192 : 0), h);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel times (gpbc_profile_begin / _end) of the BSW07 and AFP25 decrypt legs of bench.py at 1/4 of the BASELINE sizes.
     python tools/leg_profile.py"""
-import ctypes, os, sys
+import ctypes, os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -14,11 +14,12 @@ stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 def profiled(name, fn):
     fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); wall = (time.perf_counter() - t0) * 1e3
     _lib.check(lib.gpbc_profile_begin(stream))
     fn()
     names = ctypes.create_string_buffer(32 * 32); ms = (ctypes.c_double * 32)(); cnt = (ctypes.c_int * 32)(); nk = ctypes.c_int(0)
     _lib.check(lib.gpbc_profile_end(names, ms, cnt, 32, ctypes.byref(nk)))
-    print("%s: %.2f ms in kernels" % (name, sum(ms[i] for i in range(nk.value))))
+    print("%s: %.2f ms between the stream's profile marks, %.2f ms wall clock for the call" % (name, sum(ms[i] for i in range(nk.value)), wall))
     for i in range(nk.value):
         print("   %-30s %9.3f ms  x%d" % (names.raw[32 * i:32 * i + 32].split(b"\0")[0].decode(), ms[i], cnt[i]))
 

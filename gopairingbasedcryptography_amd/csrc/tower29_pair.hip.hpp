@@ -111,6 +111,24 @@ template <class X> GPBC_INLINE F6 f12p_mul_034(const X &x, const F6 &h, const F2
                                                                          // here: this runs beside the lines stream, see fe29.hip.hpp)
 }
 
+// Product of two lines, (c0 + (c3 + c4 v) w)(d0 + (d3 + d4 v) w), as a lane-pair value:
+//   C0 = (c0 d0 + xi c4 d4,  c3 d3,  c3 d4 + c4 d3),   C1 = (c0 d3 + c3 d0,  c0 d4 + c4 d0,  0)
+// (gnark's Mul034By034).  Six F2 products with Karatsuba for the three cross sums, three per lane:
+//   even  A = c0 d0,  B = c3 d3,  C = (c3+c4)(d3+d4);     odd  D = c4 d4,  E = (c0+c3)(d0+d3),  F = (c0+c4)(d0+d4)
+// then one swap.  Multiplying f by the product (f12p_mul) replaces two sparse multiplications: 3 + 9 F2 products per lane
+// instead of 8 + 8.
+template <class X> GPBC_INLINE F6 f12p_mul_034_by_034(const X &x, const F2 &c0, const F2 &c3, const F2 &c4, const F2 &d0, const F2 &d3, const F2 &d4) {
+    F2 x1 = f2_sel(x.odd, c4, c0), y1 = f2_sel(x.odd, d4, d0);
+    F2 x2 = f2_sel(x.odd, f2_norm(f2_add(c0, c3)), c3), y2 = f2_sel(x.odd, f2_norm(f2_add(d0, d3)), d3);
+    F2 x3 = f2_norm(f2_add(f2_sel(x.odd, c0, c3), c4)), y3 = f2_norm(f2_add(f2_sel(x.odd, d0, d3), d4));
+    F6 mine{f2_mul(x1, y1), f2_mul(x2, y2), f2_mul(x3, y3)};           // even (A, B, C)   odd (D, E, F)
+    F6 other = x.swap(mine);
+    // even: b0 = A + xi D, b1 = B, b2 = C - B - D        odd: b0 = E - A - B, b1 = F - A - D, b2 = 0
+    F2 t = f2_sub(f2_sub(mine.b2, other.b0), f2_sel(x.odd, mine.b0, mine.b1));
+    F2 u = f2_sel(x.odd, f2_sub(f2_sub(mine.b1, other.b0), other.b1), f2_add(mine.b0, f2_mul_xi(other.b0)));
+    return f6_reduce_arith(f6_norm(F6{u, f2_sel(x.odd, t, mine.b1), f2_sel(x.odd, f2_zero(), t)}));
+}
+
 // full product (Karatsuba over F6).  The third product (a0+a1)(b0+b1) is itself split: the even lane computes its three
 // diagonal F2 products, the odd lane its three cross products.
 template <class X> GPBC_INLINE F6 f12p_mul(const X &x, const F6 &hx, const F6 &hy) {

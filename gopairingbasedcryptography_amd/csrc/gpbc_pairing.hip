@@ -100,6 +100,9 @@ GPBC_KERNEL k_miller_accumulate_chunks(const uint8_t *__restrict__ P, const uint
 // once (k_g1_internal), and the accumulator kernel evaluates a line at its own P (two Fp x Fp2 products) right before the
 // sparse multiplication.  Lane pairs are numbered chunk-major (t = c * k + j): the 32 lane pairs of a wave then work on
 // the same Q_i at the same time, so their line loads are one broadcast transaction.
+// A chunk here may be much longer than MULTI_CHUNK: the lines live once per Q_i, not once per (pair, slot), so the only cost of a
+// long chunk is fewer lane pairs — and every pair beyond the first of a chunk saves its 64 squarings.
+constexpr int FIXED_Q_CHUNK = 64;
 GPBC_KERNEL k_q_lines(const uint8_t *__restrict__ Q, int32_t *__restrict__ qlines, size_t m) {
     size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= m) return;
@@ -128,7 +131,7 @@ GPBC_KERNEL k_miller_accumulate_fixed_q(const int32_t *__restrict__ Pint, const 
     PairDpp x{(bool)(lane & 1)};
     const size_t c = t / k, j = t % k;
     const size_t lo = c * L, hi = (c + 1) * L < m ? (c + 1) * L : m;
-    int vi[MULTI_CHUNK], n = 0;
+    int vi[FIXED_Q_CHUNK], n = 0;
     for (size_t i = lo; i < hi; i++)
         if (!Pint[(j * m + i) * 20 + 18] && !g2_bytes_inf(Q + i * GPBC_G2_BYTES)) vi[n++] = (int)i;
     F6 h;
@@ -508,13 +511,23 @@ int gpbc_multi_pair_fixed_q_dev(const void *dP, const void *dQ, size_t m, size_t
     if (!dP || !dQ || !d_gt_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
     TRY(bind_device());
     hipStream_t st = (hipStream_t)stream;
-    // chunk of the Q list per lane pair: long enough to share squarings, short enough that >= ~65536 lane pairs exist
-    size_t L = (m * k + 65535) / 65536;
-    if (g_multi_chunk.load() > 0) L = (size_t)g_multi_chunk.load();
-    if (L < 1) L = 1;
-    if (L > (size_t)MULTI_CHUNK) L = MULTI_CHUNK;
-    if (L > m) L = m;
-    const size_t n_c = (m + L - 1) / L;
+    // Chunks of the Q list per lane pair: n_c equal chunks of L = ceil(m / n_c) <= FIXED_Q_CHUNK pairs.  One lane pair costs about
+    // L line steps + 0.7 (its 64 squarings, in units of one pair's 88 line steps) and the chip runs 65536 lane pairs at a time, so
+    // the estimate to minimise is  ceil(n_c k / 65536) * (L + 0.7): long chunks share squarings, but a last partly filled round of
+    // long chunks costs as much as a full one.
+    size_t n_c = 0, L = 0;
+    if (g_multi_chunk.load() > 0) {
+        L = (size_t)g_multi_chunk.load() < m ? (size_t)g_multi_chunk.load() : m;
+        n_c = (m + L - 1) / L;
+    } else {
+        double best = 0;
+        for (size_t c = (m + FIXED_Q_CHUNK - 1) / FIXED_Q_CHUNK; c <= m; c++) {
+            const size_t len = (m + c - 1) / c, rounds = (c * k + 65535) / 65536;
+            const double cost = (double)rounds * ((double)len + 0.7);
+            if (!n_c || cost < best) { best = cost; n_c = c; L = len; }
+            if (len == 1) break;
+        }
+    }
     {
         const size_t pint_bytes = m * k * 20 * sizeof(int32_t), part_bytes = n_c * k * GPBC_GT_BYTES;
         Scratch tmp;

@@ -96,9 +96,9 @@ GPBC_KERNEL k_miller_accumulate_chunks(const uint8_t *__restrict__ P, const uint
 
 // Fixed-Q multi-pairing (gpbc_multi_pair_fixed_q): k segments pair their own m points P[j*m + i] with ONE shared list
 // Q[0..m) — a BSW07 key against k ciphertexts, a public key against k signatures.  The raw line coefficients of every Q_i
-// are computed once (k_q_lines: 88 x 54 int32 per Q_i, laid out [line][word][i]), the P's are converted to internal form
-// once (k_g1_internal), and the accumulator kernel evaluates a line at its own P (two Fp x Fp2 products) right before the
-// sparse multiplication.  Lane pairs are numbered chunk-major (t = c * k + j): the 32 lane pairs of a wave then work on
+// are computed once (k_q_lines: 88 x 54 int32 per Q_i, laid out [line][word][i]) and scaled to c0 = 1 (k_q_lines_scale), the
+// P's become (x/y, 1/y) in internal form once (k_g1_line_point), and the accumulator kernel evaluates a line at its own P (two
+// Fp x Fp2 products, one per lane of the pair) right before the sparse multiplication.  Lane pairs are numbered chunk-major (t = c * k + j): the 32 lane pairs of a wave then work on
 // the same Q_i at the same time, so their line loads are one broadcast transaction.
 // A chunk here may be much longer than MULTI_CHUNK: the lines live once per Q_i, not once per (pair, slot), so the only cost of a
 // long chunk is fewer lane pairs — and every pair beyond the first of a chunk saves its 64 squarings.
@@ -112,18 +112,56 @@ GPBC_KERNEL k_q_lines(const uint8_t *__restrict__ Q, int32_t *__restrict__ qline
     int step = 0;
     miller_lines_raw(b, [&](const LineE &l) { line_store(qlines, m, i, step++, LineS{l.r0, l.r1, l.r2}); });
 }
-GPBC_KERNEL_G1 k_g1_internal(const uint8_t *__restrict__ P, int32_t *__restrict__ out, size_t n) {
-    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const uint8_t *pb = P + i * GPBC_G1_BYTES;
-    AffP<Fe> a{fe_load(pb), fe_load(pb + 32), g1_bytes_inf(pb)};
-    int32_t *o = out + i * 20;                                    // x (9), y (9), infinity flag, pad
+// Scaling of the table to c0 = 1: line (r0, r1, r2) -> (r1 / r0, r2 / r0), one lane per (Q_i, line).  The factor 1 / r0 lies in
+// Fp2, a proper subfield of Fp12: the final exponentiation removes it, so the GT values are unchanged bit for bit while every
+// sparse product in the accumulator loses its three F2 products by c0.  (r0 = 0 only for points outside the order-r subgroup —
+// 2-torsion, or a chord through T = +-Q; the inverse of zero is zero here and the line degenerates to one: no fault, and bn254.Pair
+// promises nothing for such inputs either.)  Compact layout [line][36 words][i].
+constexpr int LINE34_WORDS = 4 * NL;
+GPBC_KERNEL k_q_lines_scale(const int32_t *__restrict__ qlines, int32_t *__restrict__ q34, size_t m) {
+    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= m * MILLER_LINES) return;
+    const size_t i = t % m;
+    const int li = (int)(t / m);
+    LineS r = line_load(qlines, m, i, li);
+    F2 inv = f2_inv(f2_norm(r.c0));                              // the raw coefficients come un-normalised from the point formulas
+    F2 c3 = f2_mul(f2_norm(r.c3), inv), c4 = f2_mul(f2_norm(r.c4), inv);
+    int32_t *o = q34 + (size_t)li * LINE34_WORDS * m + i;
+    const Fe *fe[4] = {&c3.a0, &c3.a1, &c4.a0, &c4.a1};
 #pragma unroll
-    for (int w = 0; w < NL; w++) { o[w] = a.x.v[w]; o[NL + w] = a.y.v[w]; }
-    o[18] = a.inf ? 1 : 0;
-    o[19] = 0;
+    for (int e = 0; e < 4; e++)
+#pragma unroll
+        for (int w = 0; w < NL; w++) o[(size_t)(e * NL + w) * m] = fe[e]->v[w];
 }
-GPBC_KERNEL k_miller_accumulate_fixed_q(const int32_t *__restrict__ Pint, const uint8_t *__restrict__ Q, const int32_t *__restrict__ qlines,
+__device__ __forceinline__ Line34 line34_load(const int32_t *__restrict__ buf, size_t stride, size_t lane, int step) {
+    const int32_t *b = buf + (size_t)step * LINE34_WORDS * stride + lane;
+    Line34 l;
+    Fe *fe[4] = {&l.c3.a0, &l.c3.a1, &l.c4.a0, &l.c4.a1};
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+#pragma unroll
+        for (int w = 0; w < NL; w++) fe[e]->v[w] = b[(size_t)(e * NL + w) * stride];
+    return l;
+}
+// The evaluation point of such a line: (x / y, 1 / y) in internal limbs (the division by yP is the Fp factor that makes c0 = 1).
+// 20 int32 per point: x/y (9), 1/y (9), infinity flag, pad.  One lane converts LINE_POINT_GROUP consecutive points with ONE Fp
+// inversion (fe_batch_inverse); a zero y — infinity, or a point outside the group — does not spoil its neighbours.
+constexpr int LINE_POINT_GROUP = 8;
+GPBC_KERNEL_G1 k_g1_line_point(const uint8_t *__restrict__ P, int32_t *__restrict__ out, size_t n) {
+    const size_t base = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * LINE_POINT_GROUP;
+    if (base >= n) return;
+    const int cnt = n - base < (size_t)LINE_POINT_GROUP ? (int)(n - base) : LINE_POINT_GROUP;
+    fe_batch_inverse<LINE_POINT_GROUP>(cnt, [&](int j) { return fe_load(P + (base + j) * GPBC_G1_BYTES + 32); }, [&](int j, const Fe &yinv) {
+        const uint8_t *pb = P + (base + j) * GPBC_G1_BYTES;
+        Fe xoy = fe_mul(fe_load(pb), yinv);
+        int32_t *o = out + (base + j) * 20;
+#pragma unroll
+        for (int w = 0; w < NL; w++) { o[w] = xoy.v[w]; o[NL + w] = yinv.v[w]; }
+        o[18] = g1_bytes_inf(pb) ? 1 : 0;
+        o[19] = 0;
+    });
+}
+GPBC_KERNEL k_miller_accumulate_fixed_q(const int32_t *__restrict__ Pint, const uint8_t *__restrict__ Q, const int32_t *__restrict__ q34,
                                         uint8_t *__restrict__ f_out, size_t m, size_t k, size_t L, size_t n_c) {
     size_t lane = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     size_t t = lane >> 1;
@@ -136,17 +174,17 @@ GPBC_KERNEL k_miller_accumulate_fixed_q(const int32_t *__restrict__ Pint, const 
         if (!Pint[(j * m + i) * 20 + 18] && !g2_bytes_inf(Q + i * GPBC_G2_BYTES)) vi[n++] = (int)i;
     F6 h;
     if (n == 0) h = f12p_one(x);
-    else h = miller_accumulate_multi(x, n, [&](int p, int li) -> LineS {
+    else h = miller_accumulate_multi_34(x, n, [&](int p, int li) -> Line34 {
         const size_t i = (size_t)vi[p];
-        LineS r = line_load(qlines, m, i, li);                    // raw (r0, r1, r2) of Q_i: the same address for the whole wave
+        Line34 r = line34_load(q34, m, i, li);                    // (r1 / r0, r2 / r0) of Q_i: the same address for the whole wave
         const int32_t *pp = Pint + (j * m + i) * 20;
-        // the line at P: c0 = r0 * yP, c3 = r1 * xP.  Both lanes of the pair need both; each computes ONE of the two Fp x Fp2
-        // products (even lane c0, odd lane c3) and they swap — half the evaluation work of computing both on both lanes
+        // the line at P: c3 = (r1 / r0) (xP / yP), c4 = (r2 / r0) / yP.  Both lanes of the pair need both; each computes ONE of the
+        // two Fp x Fp2 products (even lane c3, odd lane c4) and they swap
         Fe pc;
 #pragma unroll
-        for (int w = 0; w < NL; w++) pc.v[w] = x.odd ? pp[w] : pp[NL + w];            // odd: xP, even: yP
-        const F2 mine = f2_mul_fe(f2_sel(x.odd, r.c3, r.c0), pc), other = x.swap(mine);
-        return LineS{f2_sel(x.odd, other, mine), f2_sel(x.odd, mine, other), r.c4};
+        for (int w = 0; w < NL; w++) pc.v[w] = x.odd ? pp[NL + w] : pp[w];            // odd: 1 / yP, even: xP / yP
+        const F2 mine = f2_mul_fe(f2_sel(x.odd, r.c4, r.c3), pc), other = x.swap(mine);
+        return Line34{f2_sel(x.odd, other, mine), f2_sel(x.odd, mine, other)};
     });
     f6_store(f_out + (j * n_c + c) * GPBC_GT_BYTES + (x.odd ? 192 : 0), h);     // segment-major: chunks of a segment are adjacent
 }
@@ -512,8 +550,8 @@ int gpbc_multi_pair_fixed_q_dev(const void *dP, const void *dQ, size_t m, size_t
     TRY(bind_device());
     hipStream_t st = (hipStream_t)stream;
     // Chunks of the Q list per lane pair: n_c equal chunks of L = ceil(m / n_c) <= FIXED_Q_CHUNK pairs.  One lane pair costs about
-    // L line steps + 0.7 (its 64 squarings, in units of one pair's 88 line steps) and the chip runs 65536 lane pairs at a time, so
-    // the estimate to minimise is  ceil(n_c k / 65536) * (L + 0.7): long chunks share squarings, but a last partly filled round of
+    // L line steps + 0.85 (its 64 squarings, in units of one pair's 88 line steps) and the chip runs 65536 lane pairs at a time, so
+    // the estimate to minimise is  ceil(n_c k / 65536) * (L + 0.85): long chunks share squarings, but a last partly filled round of
     // long chunks costs as much as a full one.
     size_t n_c = 0, L = 0;
     if (g_multi_chunk.load() > 0) {
@@ -523,24 +561,29 @@ int gpbc_multi_pair_fixed_q_dev(const void *dP, const void *dQ, size_t m, size_t
         double best = 0;
         for (size_t c = (m + FIXED_Q_CHUNK - 1) / FIXED_Q_CHUNK; c <= m; c++) {
             const size_t len = (m + c - 1) / c, rounds = (c * k + 65535) / 65536;
-            const double cost = (double)rounds * ((double)len + 0.7);
+            const double cost = (double)rounds * ((double)len + 0.85);
             if (!n_c || cost < best) { best = cost; n_c = c; L = len; }
             if (len == 1) break;
         }
     }
     {
         const size_t pint_bytes = m * k * 20 * sizeof(int32_t), part_bytes = n_c * k * GPBC_GT_BYTES;
+        const size_t q34_bytes = m * (size_t)MILLER_LINES * LINE34_WORDS * sizeof(int32_t);
         Scratch tmp;
-        TRY(tmp.open(st, 0, Scratch::padded(m * LINE_BYTES_PER_PAIR) + Scratch::padded(pint_bytes) + Scratch::padded(part_bytes)));
-        int32_t *dLines = tmp.take<int32_t>(m * LINE_BYTES_PER_PAIR), *dPint = tmp.take<int32_t>(pint_bytes);
+        TRY(tmp.open(st, 0, Scratch::padded(m * LINE_BYTES_PER_PAIR) + Scratch::padded(q34_bytes) + Scratch::padded(pint_bytes) + Scratch::padded(part_bytes)));
+        int32_t *dLines = tmp.take<int32_t>(m * LINE_BYTES_PER_PAIR), *dQ34 = tmp.take<int32_t>(q34_bytes), *dPint = tmp.take<int32_t>(pint_bytes);
         uint8_t *dPart = tmp.take(part_bytes);
+        HIP_TRY(hipMemsetAsync(dLines, 0, m * LINE_BYTES_PER_PAIR, st));           // rows of points at infinity are never written, but are scaled
         k_q_lines<<<grid_for(m), BLOCK, 0, st>>>((const uint8_t *)dQ, dLines, m);
         TRY(check_launch("k_q_lines"));
         profile_mark("k_q_lines", st);
-        k_g1_internal<<<grid_for(m * k), BLOCK, 0, st>>>((const uint8_t *)dP, dPint, m * k);
-        TRY(check_launch("k_g1_internal"));
-        profile_mark("k_g1_internal", st);
-        k_miller_accumulate_fixed_q<<<grid_for(2 * n_c * k), BLOCK, 0, st>>>(dPint, (const uint8_t *)dQ, dLines, dPart, m, k, L, n_c);
+        k_q_lines_scale<<<grid_for(m * MILLER_LINES), BLOCK, 0, st>>>(dLines, dQ34, m);
+        TRY(check_launch("k_q_lines_scale"));
+        profile_mark("k_q_lines_scale", st);
+        k_g1_line_point<<<grid_for((m * k + LINE_POINT_GROUP - 1) / LINE_POINT_GROUP), BLOCK, 0, st>>>((const uint8_t *)dP, dPint, m * k);
+        TRY(check_launch("k_g1_line_point"));
+        profile_mark("k_g1_line_point", st);
+        k_miller_accumulate_fixed_q<<<grid_for(2 * n_c * k), BLOCK, 0, st>>>(dPint, (const uint8_t *)dQ, dQ34, dPart, m, k, L, n_c);
         TRY(check_launch("k_miller_accumulate_fixed_q"));
         profile_mark("k_miller_accumulate_fixed_q", st);
         k_chunk_product<<<grid_for(k), BLOCK, 0, st>>>(dPart, (uint8_t *)d_gt_out, k, n_c);      // ciphertext j owns chunk values [j n_c, (j+1) n_c)

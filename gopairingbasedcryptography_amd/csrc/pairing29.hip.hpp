@@ -108,6 +108,29 @@ template <class Sink> GPBC_INLINE void miller_lines_raw(const G2A &q, Sink &&sin
     sink(l);
 }
 
+// 1 / y_j for cnt <= G values by ONE inversion (Montgomery's trick: prefix products, invert, walk back); a zero takes the place
+// of a one in the chain so that it cannot spoil its neighbours (its own result is then 1 — the caller flags such points).
+// y(j) yields the j-th value (canonical), emit(j, inverse) receives the results, last first.
+template <int G, class LoadY, class Emit> GPBC_INLINE void fe_batch_inverse(int cnt, LoadY &&y_at, Emit &&emit) {
+    Fe y[G], pre[G];
+#pragma unroll
+    for (int j = 0; j < G; j++) {
+        y[j] = fe_one();
+        if (j < cnt) {
+            Fe v = y_at(j);
+            if (!fe_is_zero(v)) y[j] = v;
+        }
+        pre[j] = j ? fe_mul(pre[j - 1], y[j]) : y[j];
+    }
+    Fe inv = fe_inv(pre[G - 1]);
+#pragma unroll
+    for (int j = G - 1; j >= 0; j--) {
+        Fe r = j ? fe_mul(inv, pre[j - 1]) : inv;
+        inv = fe_mul(inv, y[j]);
+        if (j < cnt) emit(j, r);
+    }
+}
+
 GPBC_INLINE F12 f12_from_line(const LineS &l) {
     return F12{F6{l.c0, f2_zero(), f2_zero()}, F6{l.c3, l.c4, f2_zero()}};
 }

@@ -66,6 +66,27 @@ template <class X, class LineAt> GPBC_INLINE F6 miller_accumulate_multi(const X 
     return h;
 }
 
+// The same for lines scaled to c0 = 1 (fixed-Q table: Line34 = the w and vw coefficients).  With five F2 products per lane a
+// sparse product is cheaper than half of (line product + full product), so the lines enter one by one.
+struct Line34 { F2 c3, c4; };
+template <class X, class LineAt> GPBC_INLINE F6 miller_accumulate_multi_34(const X &x, int m, LineAt &&line) {
+    int li = 0;
+    auto mul_lines = [&](F6 h, int from) {
+        for (int p = from; p < m; p++) { Line34 l = line(p, li); h = f12p_mul_34(x, h, l.c3, l.c4); }
+        li++;
+        return h;
+    };
+    Line34 l0 = line(0, li);
+    F6 h = f6_sel(x.odd, F6{l0.c3, l0.c4, f2_zero()}, F6{f2_one(), f2_zero(), f2_zero()});
+    h = mul_lines(h, 1);
+    for (int i = BN254_ATE_NAF_LEN - 2; i >= 0; i--) {
+        if (i != BN254_ATE_NAF_LEN - 2) h = mul_lines(f12p_sqr(x, h), 0);
+        if (ate_naf_digit(i) != 0) h = mul_lines(h, 0);
+    }
+    for (int k = 0; k < 2; k++) h = mul_lines(h, 0);
+    return h;
+}
+
 // n squarings in place, each value-reduced once on its outputs (its xi products are only normalised)
 template <class X> GPBC_INLINE F6 f12p_cyclo_sqr_n(const X &x, F6 r, int n) {
     for (int i = 0; i < n; i++) r = f12p_cyclo_sqr<true>(x, r);

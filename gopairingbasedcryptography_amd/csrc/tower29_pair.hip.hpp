@@ -111,6 +111,16 @@ template <class X> GPBC_INLINE F6 f12p_mul_034(const X &x, const F6 &h, const F2
                                                                          // here: this runs beside the lines stream, see fe29.hip.hpp)
 }
 
+// f * (1 + l1 w), l1 = (c3, c4, 0) — a line scaled to c0 = 1 (what the fixed-Q line table holds; the scaling factor lies in Fp2
+// and the final exponentiation removes it):  C0' = a + v (b l1),  C1' = b + a l1.  Five F2 products per lane instead of eight.
+template <class X> GPBC_INLINE F6 f12p_mul_34(const X &x, const F6 &h, const F2 &c3, const F2 &c4) {
+    F2 s34 = f2_norm(f2_add(c3, c4));
+    F6 r1 = f6_mul_01_t<false, false>(h, c3, c4, s34);
+    F6 p1 = x.swap(r1);
+    F6 add = f6_sel(x.odd, p1, f6_mul_v_t<false>(p1));
+    return f6_reduce_arith(f6_norm(f6_add(h, add)));
+}
+
 // Product of two lines, (c0 + (c3 + c4 v) w)(d0 + (d3 + d4 v) w), as a lane-pair value:
 //   C0 = (c0 d0 + xi c4 d4,  c3 d3,  c3 d4 + c4 d3),   C1 = (c0 d3 + c3 d0,  c0 d4 + c4 d0,  0)
 // (gnark's Mul034By034).  Six F2 products with Karatsuba for the three cross sums, three per lane:

@@ -231,25 +231,31 @@ void hc_pair_lanes_multi(const uint8_t *P, const uint8_t *Q, size_t n, uint8_t *
     lane(false);
     t1.join();
 }
-// fixed-Q multi-pairing exactly as k_q_lines + k_miller_accumulate_fixed_q do it: the RAW line coefficients of every Q_i
-// (miller_lines_raw), evaluated at P_i inside the accumulator (two Fp x Fp2 products per line), shared squarings on one lane
-// pair; out = the Miller value of prod e(P_i, Q_i) before the final exponentiation (do_final_exp = 0) or the GT value
+// fixed-Q multi-pairing exactly as k_q_lines + k_q_lines_scale + k_g1_line_point + k_miller_accumulate_fixed_q do it: the RAW line
+// coefficients of every Q_i (miller_lines_raw) scaled to c0 = 1, evaluated at (xP / yP, 1 / yP) inside the accumulator (one
+// Fp x Fp2 product per lane, swapped), shared squarings on one lane pair; out = the Miller value of prod e(P_i, Q_i) up to a
+// factor in Fp2 (do_final_exp = 0: the caller applies the final exponentiation, which removes it) or the GT value
 void hc_pair_fixed_q(const uint8_t *P, const uint8_t *Q, size_t n, uint8_t *out, int do_final_exp) {
-    std::vector<LineE> raw(n * MILLER_LINES);
-    std::vector<G1A> pts(n);
+    std::vector<Line34> tab(n * MILLER_LINES);
+    std::vector<G1A> pts(n);                                    // (x / y, 1 / y)
+    for (size_t base = 0; base < n; base += 8)                  // k_g1_line_point: groups of 8 points share one inversion
+        fe_batch_inverse<8>(n - base < 8 ? (int)(n - base) : 8, [&](int j) { return fe_load(P + 64 * (base + j) + 32); },
+                            [&](int j, const Fe &yinv) { pts[base + j] = G1A{fe_mul(fe_load(P + 64 * (base + j)), yinv), yinv}; });
     for (size_t i = 0; i < n; i++) {
-        pts[i] = G1A{fe_load(P + 64 * i), fe_load(P + 64 * i + 32)};
         G2A b{f2_load(Q + 128 * i), f2_load(Q + 128 * i + 64)};
         int cnt = 0;
-        miller_lines_raw(b, [&](const LineE &l) { raw[i * MILLER_LINES + cnt++] = l; });
+        miller_lines_raw(b, [&](const LineE &l) {
+            F2 inv = f2_inv(f2_norm(l.r0));
+            tab[i * MILLER_LINES + cnt++] = Line34{f2_mul(f2_norm(l.r1), inv), f2_mul(f2_norm(l.r2), inv)};
+        });
     }
     PairRendezvous rv;
     auto lane = [&](bool odd) {
         PairHost x{odd, &rv};
-        F6 h = miller_accumulate_multi(x, (int)n, [&](int p, int li) -> LineS {
-            const LineE &r = raw[(size_t)p * MILLER_LINES + li];
-            const F2 mine = f2_mul_fe(x.odd ? r.r1 : r.r0, x.odd ? pts[p].x : pts[p].y), other = x.swap(mine);   // one product per lane, swapped
-            return LineS{x.odd ? other : mine, x.odd ? mine : other, r.r2};
+        F6 h = miller_accumulate_multi_34(x, (int)n, [&](int p, int li) -> Line34 {
+            const Line34 &r = tab[(size_t)p * MILLER_LINES + li];
+            const F2 mine = f2_mul_fe(x.odd ? r.c4 : r.c3, x.odd ? pts[p].y : pts[p].x), other = x.swap(mine);   // one product per lane, swapped
+            return Line34{x.odd ? other : mine, x.odd ? mine : other};
         });
         if (do_final_exp) h = final_exp_pair(x, h);
         f6_store(out + (odd ? 192 : 0), h);

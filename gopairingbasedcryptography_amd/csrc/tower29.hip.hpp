@@ -58,14 +58,44 @@ GPBC_INLINE F2 f2_from_vec(const i32x18 &v) {
     for (int i = 0; i < NL; i++) { r.a0.v[i] = v[i]; r.a1.v[i] = v[NL + i]; }
     return r;
 }
+// An F2 product has 36 operand limbs and the calling convention 31 argument VGPRs (v31 carries the work-item id).  The last
+// five used to travel through the stack, i.e. private memory — and the PMC counters show that on this machine every
+// private-memory access of these kernels reaches HBM (profiles/r02_final_pmc_traffic.json: k_final_exp wrote 17 KB and fetched
+// 20 KB per lane, its dynamic count of scratch stores and loads times four bytes): ten HBM transactions per product, more than
+// half of the kernel's traffic.  They go through LDS instead: a 16-byte and a 4-byte slot per lane of the (64-thread) workgroup,
+// written by the caller right before the call and read first thing by the leaf, in order on the wave's LDS queue.  The slot is
+// addressed by the lane number from v_mbcnt (= threadIdx.x of a one-wave workgroup).
+// -DGPBC_F2_ARGS_ON_STACK restores the stack form for A/B measurements (tools/variant_bench.sh).
+#ifdef GPBC_F2_ARGS_ON_STACK
 template <bool NORM> __device__ __noinline__ i32x18 f2_mul_leaf(GPBC_ARGS9(a), GPBC_ARGS9(b), GPBC_ARGS9(c), GPBC_ARGS9(d)) {
     return f2_to_vec(f2_mul_core<NORM>(GPBC_PACK_F2(a, b), GPBC_PACK_F2(c, d)));
 }
+template <bool NORM> GPBC_INLINE F2 f2_mul_call(const F2 &x, const F2 &y) {
+    return f2_from_vec(f2_mul_leaf<NORM>(GPBC_PASS9(x.a0), GPBC_PASS9(x.a1), GPBC_PASS9(y.a0), GPBC_PASS9(y.a1)));
+}
+#else
+typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+__shared__ i32x4 g_f2_arg_slot[64];
+__shared__ int32_t g_f2_arg_slot4[64];
+GPBC_INLINE unsigned f2_arg_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+template <bool NORM> __device__ __noinline__ i32x18 f2_mul_leaf(GPBC_ARGS9(a), GPBC_ARGS9(b), GPBC_ARGS9(c), int32_t d0, int32_t d1, int32_t d2, int32_t d3) {
+    const unsigned lane = f2_arg_lane();
+    const i32x4 t = g_f2_arg_slot[lane];
+    const int32_t d4 = g_f2_arg_slot4[lane], d5 = t.x, d6 = t.y, d7 = t.z, d8 = t.w;
+    return f2_to_vec(f2_mul_core<NORM>(GPBC_PACK_F2(a, b), GPBC_PACK_F2(c, d)));
+}
+template <bool NORM> GPBC_INLINE F2 f2_mul_call(const F2 &x, const F2 &y) {
+    const unsigned lane = f2_arg_lane();
+    g_f2_arg_slot[lane] = i32x4{y.a1.v[5], y.a1.v[6], y.a1.v[7], y.a1.v[8]};
+    g_f2_arg_slot4[lane] = y.a1.v[4];
+    return f2_from_vec(f2_mul_leaf<NORM>(GPBC_PASS9(x.a0), GPBC_PASS9(x.a1), GPBC_PASS9(y.a0), y.a1.v[0], y.a1.v[1], y.a1.v[2], y.a1.v[3]));
+}
+#endif
 template <bool NORM> __device__ __noinline__ i32x18 f2_sqr_leaf(GPBC_ARGS9(a), GPBC_ARGS9(b)) {
     return f2_to_vec(f2_sqr_core<NORM>(GPBC_PACK_F2(a, b)));
 }
-GPBC_INLINE F2 f2_mul(const F2 &x, const F2 &y) { return f2_from_vec(f2_mul_leaf<false>(GPBC_PASS9(x.a0), GPBC_PASS9(x.a1), GPBC_PASS9(y.a0), GPBC_PASS9(y.a1))); }
-GPBC_INLINE F2 f2_mul_nn(const F2 &x, const F2 &y) { return f2_from_vec(f2_mul_leaf<true>(GPBC_PASS9(x.a0), GPBC_PASS9(x.a1), GPBC_PASS9(y.a0), GPBC_PASS9(y.a1))); }
+GPBC_INLINE F2 f2_mul(const F2 &x, const F2 &y) { return f2_mul_call<false>(x, y); }
+GPBC_INLINE F2 f2_mul_nn(const F2 &x, const F2 &y) { return f2_mul_call<true>(x, y); }
 GPBC_INLINE F2 f2_sqr(const F2 &x) { return f2_from_vec(f2_sqr_leaf<false>(GPBC_PASS9(x.a0), GPBC_PASS9(x.a1))); }
 GPBC_INLINE F2 f2_sqr_n(const F2 &x) { return f2_from_vec(f2_sqr_leaf<true>(GPBC_PASS9(x.a0), GPBC_PASS9(x.a1))); }
 #else

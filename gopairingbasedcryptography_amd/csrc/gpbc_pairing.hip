@@ -462,7 +462,7 @@ static int check_segments(const uint64_t *seg_off, size_t k, size_t *n_pairs) {
 // chunk values are released on return).
 static std::atomic<int> g_multi_chunk{0};
 int gpbc_set_multi_pair_chunk(int pairs_per_chunk) {
-    if (pairs_per_chunk < 0 || pairs_per_chunk > MULTI_CHUNK) return fail(GPBC_ERR_INVALID_ARG, "chunk length must be 0 (automatic) .. %d", MULTI_CHUNK);
+    if (pairs_per_chunk < 0 || pairs_per_chunk > FIXED_Q_CHUNK) return fail(GPBC_ERR_INVALID_ARG, "chunk length must be 0 (automatic) .. %d", FIXED_Q_CHUNK);
     g_multi_chunk.store(pairs_per_chunk);
     return GPBC_OK;
 }
@@ -477,7 +477,7 @@ static int multi_pair_core(const uint8_t *dP, const uint8_t *dQ, const uint64_t 
     for (size_t j = 0; j < k; j++) if (seg_off[j + 1] - seg_off[j] > max_len) max_len = seg_off[j + 1] - seg_off[j];
     uint64_t L = (n_pairs + 131071) / 131072;
     if (max_len <= (uint64_t)MULTI_CHUNK) L = k >= MULTI_GROUP ? max_len : 1;      // short segments: whole or not at all
-    if (g_multi_chunk.load() > 0) L = (uint64_t)g_multi_chunk.load();
+    if (g_multi_chunk.load() > 0) L = (uint64_t)g_multi_chunk.load();                 // (capped at MULTI_CHUNK below)
     if (L <= 1 && g_multi_chunk.load() <= 0) {
         // nothing to share (few pairs, or single-pair segments): one Miller loop per lane pair and one product per segment
         {

@@ -125,7 +125,8 @@ int gpbc_multi_pair_hostseg_dev(const void *dP, const void *dQ, const uint64_t *
  * `stream`; its temporaries (line table, converted points, chunk values) stay in a per-stream scratch buffer between calls. */
 int gpbc_multi_pair_fixed_q(const void *P, const void *Q, size_t m, size_t k, void *gt_out);
 int gpbc_multi_pair_fixed_q_dev(const void *dP, const void *dQ, size_t m, size_t k, void *d_gt_out, void *stream);
-/* Tuning / test knob of that path: pairs per shared-squaring chunk, 1..8; 0 (default) = chosen from the batch size. */
+/* Tuning / test knob of the multi-pairing paths: pairs per shared-squaring chunk, 1..64 (the general path, whose lines live in a
+ * per-slot workspace, caps it at 8; the fixed-Q path takes all of it); 0 (default) = chosen from the batch size. */
 int gpbc_set_multi_pair_chunk(int pairs_per_chunk);
 
 /* bn254.PairingCheck(P, Q) (bool, error), k times (signature/bls01_signature/bls_signature.go:81):

@@ -159,6 +159,19 @@ def test_multi_pair_fixed_q(eng, oracle, synth):
     assert want[5].tobytes() == o.gt_to_bytes(o.F12_ONE)
     with pytest.raises(ValueError):
         eng.multi_pair_fixed_q(Ps[:m + 1], Qs)
+    # long chunks (the BASELINE-size BSW07 decrypt runs 9 chunks of 57): 70 pairs as 64 + 6, 3 x 24 (last one short), 2 x 35
+    m, k = 70, 3
+    Qs = eng.g2_scalar_mul(Q.reshape(-1, 128)[0], [o.bench_scalar("fq-long-Q", i) for i in range(m)])
+    Ps = eng.g1_scalar_mul(P.reshape(-1, 64)[0], [o.bench_scalar("fq-long-P", i) for i in range(m * k)])
+    Qs[17] = 0
+    Ps[m + 64] = 0                               # a point at infinity inside a group of the batched inversion, in the short chunk
+    want = oracle.multi_pair(Ps, np.tile(Qs, (k, 1)), np.arange(0, m * k + 1, m).astype(np.uint64), threads=8)
+    try:
+        for chunk in (64, 24, 35):
+            _lib.check(_lib.load().gpbc_set_multi_pair_chunk(chunk))
+            assert (eng.multi_pair_fixed_q(Ps, Qs) == want).all(), chunk
+    finally:
+        _lib.load().gpbc_set_multi_pair_chunk(0)
 
 
 def test_bls_verify_flow(eng):

@@ -66,14 +66,14 @@ GPBC_INLINE LineS line_scale(const LineE &l, const G1A &p) { return LineS{f2_mul
 // sink(LineS) is called once per line, in evaluation order.  Caller has checked neither point is infinity.
 template <class Sink> GPBC_INLINE void miller_lines(const G1A &p, const G2A &q, Sink &&sink) {
     G2P t{q.x, q.y, f2_one()};
-    G2A qn{q.x, f2_neg(q.y)};
+    const F2 ny = f2_neg(q.y);
     LineE l;
     for (int i = BN254_ATE_NAF_LEN - 2; i >= 0; i--) {
         g2_double_step(t, l);
         sink(line_scale(l, p));
         int d = ate_naf_digit(i);
         if (d != 0) {
-            g2_add_step(t, l, d > 0 ? q : qn);
+            g2_add_step(t, l, G2A{q.x, f2_sel(d > 0, q.y, ny)});
             sink(line_scale(l, p));
         }
     }
@@ -89,14 +89,14 @@ template <class Sink> GPBC_INLINE void miller_lines(const G1A &p, const G2A &q, 
 // Q that is paired with many P's (a decryption key against many ciphertexts, a fixed public key) needs them once.
 template <class Sink> GPBC_INLINE void miller_lines_raw(const G2A &q, Sink &&sink) {
     G2P t{q.x, q.y, f2_one()};
-    G2A qn{q.x, f2_neg(q.y)};
+    const F2 ny = f2_neg(q.y);
     LineE l;
     for (int i = BN254_ATE_NAF_LEN - 2; i >= 0; i--) {
         g2_double_step(t, l);
         sink(l);
         int d = ate_naf_digit(i);
         if (d != 0) {
-            g2_add_step(t, l, d > 0 ? q : qn);
+            g2_add_step(t, l, G2A{q.x, f2_sel(d > 0, q.y, ny)});
             sink(l);
         }
     }

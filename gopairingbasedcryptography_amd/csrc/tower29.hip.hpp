@@ -27,6 +27,20 @@ GPBC_INLINE F2 f2_reduce(const F2 &x) { return F2{fe_reduce(x.a0), fe_reduce(x.a
 GPBC_INLINE F2 f2_halve(const F2 &x) { return F2{fe_halve(x.a0), fe_halve(x.a1)}; }
 GPBC_INLINE bool f2_is_zero(const F2 &x) { return fe_is_zero(x.a0) && fe_is_zero(x.a1); }
 
+// limb-wise selection (v_cndmask): values picked by a flag stay in registers, where `c ? a : b` on the structs makes the
+// compiler keep both in private memory and load the chosen one
+GPBC_INLINE Fe fe_sel(bool c, const Fe &a, const Fe &b) {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.v[i] = c ? a.v[i] : b.v[i];
+#ifdef GPBC_BOUNDS
+    for (int i = 0; i < NL; i++) { r.lo[i] = a.lo[i] < b.lo[i] ? a.lo[i] : b.lo[i]; r.hi[i] = a.hi[i] > b.hi[i] ? a.hi[i] : b.hi[i]; }   // must hold for either lane
+    r.vb = a.vb > b.vb ? a.vb : b.vb;
+#endif
+    return r;
+}
+GPBC_INLINE F2 f2_sel(bool c, const F2 &a, const F2 &b) { return F2{fe_sel(c, a.a0, b.a0), fe_sel(c, a.a1, b.a1)}; }
+
 // Lazy schoolbook product and complex squaring.  NORM variants first re-normalise their operands (used for the sums
 // of the Karatsuba layers above), so that the normalisation code lives inside the leaf instead of at every call site.
 template <bool NORM> GPBC_INLINE F2 f2_mul_core(const F2 &xx, const F2 &yy) {

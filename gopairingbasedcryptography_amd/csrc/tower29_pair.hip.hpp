@@ -19,17 +19,6 @@
 
 namespace gpbc {
 
-GPBC_INLINE Fe fe_sel(bool c, const Fe &a, const Fe &b) {
-    Fe r;
-#pragma unroll
-    for (int i = 0; i < NL; i++) r.v[i] = c ? a.v[i] : b.v[i];
-#ifdef GPBC_BOUNDS
-    for (int i = 0; i < NL; i++) { r.lo[i] = a.lo[i] < b.lo[i] ? a.lo[i] : b.lo[i]; r.hi[i] = a.hi[i] > b.hi[i] ? a.hi[i] : b.hi[i]; }   // must hold for either lane
-    r.vb = a.vb > b.vb ? a.vb : b.vb;
-#endif
-    return r;
-}
-GPBC_INLINE F2 f2_sel(bool c, const F2 &a, const F2 &b) { return F2{fe_sel(c, a.a0, b.a0), fe_sel(c, a.a1, b.a1)}; }
 GPBC_INLINE F6 f6_sel(bool c, const F6 &a, const F6 &b) { return F6{f2_sel(c, a.b0, b.b0), f2_sel(c, a.b1, b.b1), f2_sel(c, a.b2, b.b2)}; }
 GPBC_INLINE F6 f6_dbl(const F6 &x) { return f6_add(x, x); }
 

@@ -128,10 +128,52 @@ template <class X> GPBC_INLINE F6 f12p_mul_034_by_034(const X &x, const F2 &c0, 
     return f6_reduce_arith(f6_norm(F6{u, f2_sel(x.odd, t, mine.b1), f2_sel(x.odd, f2_zero(), t)}));
 }
 
+// One F6 value per lane parked in LDS (216 of a lane's 320-byte share at two waves per SIMD): a register spill costs an HBM
+// transaction on this machine, LDS does not.  Used where a value is computed early and needed only at the end of a
+// long stretch of leaf calls, during which just ~158 VGPRs survive a call (the leaf itself takes 98).  Layout [chunk of 4 limbs]
+// [lane]: 14 ds_write_b128 / ds_read_b128, conflict-free.  The host build of the bounds harness keeps the object (with its
+// intervals) as it is.  -DGPBC_NO_F6_PARK keeps the value in registers (A/B runs).  One slot: parked values must not nest.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GPBC_BOUNDS) && !defined(GPBC_INLINE_LEAVES) && !defined(GPBC_F2_ARGS_ON_STACK) && !defined(GPBC_NO_F6_PARK)
+__shared__ i32x4 g_f6_park[14][64];
+struct F6Park {
+    GPBC_INLINE explicit F6Park(const F6 &v) {
+        const Fe *fe[6] = {&v.b0.a0, &v.b0.a1, &v.b1.a0, &v.b1.a1, &v.b2.a0, &v.b2.a1};
+        int32_t w[56];
+#pragma unroll
+        for (int e = 0; e < 6; e++)
+#pragma unroll
+            for (int i = 0; i < NL; i++) w[e * NL + i] = fe[e]->v[i];
+        w[54] = 0; w[55] = 0;
+        const unsigned lane = f2_arg_lane();
+#pragma unroll
+        for (int c = 0; c < 14; c++) g_f6_park[c][lane] = i32x4{w[4 * c], w[4 * c + 1], w[4 * c + 2], w[4 * c + 3]};
+    }
+    GPBC_INLINE F6 get() const {
+        int32_t w[56];
+        const unsigned lane = f2_arg_lane();
+#pragma unroll
+        for (int c = 0; c < 14; c++) { i32x4 t = g_f6_park[c][lane]; w[4 * c] = t.x; w[4 * c + 1] = t.y; w[4 * c + 2] = t.z; w[4 * c + 3] = t.w; }
+        F6 v;
+        Fe *fe[6] = {&v.b0.a0, &v.b0.a1, &v.b1.a0, &v.b1.a1, &v.b2.a0, &v.b2.a1};
+#pragma unroll
+        for (int e = 0; e < 6; e++)
+#pragma unroll
+            for (int i = 0; i < NL; i++) fe[e]->v[i] = w[e * NL + i];
+        return v;
+    }
+};
+#else
+struct F6Park {                                               // host / A-B builds: the value itself (with its intervals)
+    F6 v;
+    GPBC_INLINE explicit F6Park(const F6 &x) : v(x) {}
+    GPBC_INLINE F6 get() const { return v; }
+};
+#endif
+
 // full product (Karatsuba over F6).  The third product (a0+a1)(b0+b1) is itself split: the even lane computes its three
 // diagonal F2 products, the odd lane its three cross products.
 template <class X> GPBC_INLINE F6 f12p_mul(const X &x, const F6 &hx, const F6 &hy) {
-    F6 t = f6_mul_t<false>(hx, hy);                          // even: t0 = a0 b0, odd: t1 = a1 b1
+    const F6Park parked(f6_mul_t<false>(hx, hy));            // even: t0 = a0 b0, odd: t1 = a1 b1 — needed again after the three products below
     F6 sx = f6_norm(f6_add(hx, x.swap(hx)));                // (a DPP-fused addition here measured 3 % SLOWER: the 108 inline-asm
     F6 sy = f6_norm(f6_add(hy, x.swap(hy)));                //  statements get in the scheduler's way; profiles/r02_microbench_pair.txt)
     // three F2 products per lane of sx * sy
@@ -141,6 +183,7 @@ template <class X> GPBC_INLINE F6 f12p_mul(const X &x, const F6 &hx, const F6 &h
     F6 mine{f2_mul(xa, ya), f2_mul(xb, yb), f2_mul(xc, yc)};  // even: (u0,u1,u2) diagonal, odd: (m12,m01,m02) cross
     F6 other = x.swap(mine);
     F6 dg = f6_sel(x.odd, other, mine), cr = f6_sel(x.odd, mine, other);
+    F6 t = parked.get();
     F6 pt = x.swap(t);                                        // even: t1, odd: t0
     // one shared xi-multiplication: the odd lane needs xi (m12 - u1 - u2) for m, the even lane xi t1.b2 for v t1
     F2 xi1 = f2_mul_xi_nn(f2_sel(x.odd, f2_norm(f2_sub(f2_sub(cr.b0, dg.b1), dg.b2)), pt.b2));

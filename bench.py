@@ -326,6 +326,13 @@ def main():
             uf = torch.from_numpy(wl.bench_scalars("h2c", rank * nw * 4, nw * 4).copy()).to(dev).reshape(-1, 32)   # values < r < p: valid fp.Elements
             sec["g1_map_to_curve_per_s"] = rate(bn254.map_to_g1, uf[:2 * nw].reshape(nw, 64).contiguous()) * nw / B
             sec["g2_map_to_curve_per_s"] = rate(bn254.map_to_g2, uf.reshape(nw, 128).contiguous()) * nw / B
+            # whole hash to curve of 32-byte messages resident in HBM: SHA-256 expand_message_xmd + reduction + map, one message per lane
+            hmsg = uf[:nw].reshape(-1).contiguous()
+            hoff = (torch.arange(nw + 1, dtype=torch.int64, device=dev) * 32).contiguous()
+            from gopairingbasedcryptography_amd import hash_to as _h2
+            sec["g1_hash_to_curve_per_s"] = rate(lambda m: bn254.hash_to_g1(m, _h2.DST_BYTES_G1, msg_off=hoff), hmsg) * nw / B
+            sec["g2_hash_to_curve_per_s"] = rate(lambda m: bn254.hash_to_g2(m, _h2.DST_BYTES_G2, msg_off=hoff), hmsg) * nw / B
+            sec["hash_to_field_per_s"] = rate(lambda m: bn254.hash_to_field(m, _h2.DST_BYTES_G1, 2, msg_off=hoff), hmsg) * nw / B
             fb = bn254.FixedBase(g1d)
             sec["g1_fixed_base_mults_per_s"] = rate(fb.mul, ks)
             fb.close()

@@ -688,6 +688,69 @@ def map_to_g2(u):
     return _map_fields(G2_BYTES, lib.gpbc_g2_map_to_curve_batch, lib.gpbc_g2_map_to_curve_batch_dev, u)
 
 
+def _hash_messages(what, msgs, dst, msg_off=None):
+    """Shared body of hash_to_g1 / hash_to_g2 / hash_to_field.  what: 0 G1, 1 G2, 2 / 4 field elements per message.
+    msgs: a list of bytes-like messages (host), or the concatenated bytes as a numpy array / CUDA uint8 tensor with
+    msg_off (n + 1 offsets; numpy uint64 for host data, an int64 CUDA tensor for device data)."""
+    _ensure_init()
+    lib = _lib.load()
+    dst = bytes(dst)
+    if len(dst) > 255:                                           # RFC 9380 section 5.3.3
+        import hashlib
+        dst = hashlib.sha256(b"H2C-OVERSIZE-DST-" + dst).digest()
+    width = G1_BYTES if what == 0 else G2_BYTES if what == 1 else 32 * what
+    dbuf = ctypes.create_string_buffer(dst, len(dst) if dst else 1)
+    count = (ctypes.c_int(what),) if what >= 2 else ()
+    if _is_torch(msgs):
+        import torch
+        if msg_off is None or not _is_torch(msg_off) or msg_off.dtype != torch.int64 or not msg_off.is_contiguous() or msg_off.device != msgs.device:
+            raise ValueError("device messages need msg_off as a contiguous int64 tensor on the same device")
+        n = msg_off.numel() - 1
+        if n < 0:
+            raise ValueError("msg_off needs n + 1 entries")
+        out = _tnew(msgs, n, width)
+        _tchk(msgs, (msgs, msgs.numel(), "messages"))
+        fn = (lib.gpbc_hash_to_g1_dev, lib.gpbc_hash_to_g2_dev, lib.gpbc_hash_to_field_dev)[min(what, 2)]
+        _lib.check(fn(_tptr(msgs), ctypes.c_void_p(msg_off.data_ptr()), _sz(msgs.numel()), _sz(n), dbuf, _sz(len(dst)), *count, _tptr(out), _torch_stream()))
+        return out
+    if msg_off is None:
+        msgs = [bytes(m) for m in msgs]
+        msg_off = np.zeros(len(msgs) + 1, dtype=np.uint64)
+        if msgs:
+            msg_off[1:] = np.cumsum([len(m) for m in msgs], dtype=np.uint64)
+        data = np.frombuffer(b"".join(msgs), dtype=np.uint8) if msgs and int(msg_off[-1]) else np.zeros(1, dtype=np.uint8)
+    else:
+        data = np.ascontiguousarray(np.asarray(msgs, dtype=np.uint8)).reshape(-1)
+        msg_off = np.ascontiguousarray(np.asarray(msg_off, dtype=np.uint64))
+        if msg_off.size < 1 or (msg_off.size > 1 and int(msg_off[-1]) > data.size):
+            raise ValueError("message offsets exceed the message buffer")
+        if data.size == 0:
+            data = np.zeros(1, dtype=np.uint8)
+    n = msg_off.size - 1
+    out = np.empty((n, width), dtype=np.uint8)
+    if n:
+        fn = (lib.gpbc_hash_to_g1, lib.gpbc_hash_to_g2, lib.gpbc_hash_to_field)[min(what, 2)]
+        _lib.check(fn(_ptr(data), _ptr(msg_off), _sz(n), dbuf, _sz(len(dst)), *count, _ptr(out)))
+    return out
+
+
+def hash_to_g1(msgs, dst, msg_off=None):
+    """bn254.HashToG1(msg, dst) for every message, hashing included (expand_message_xmd with SHA-256 on the device)."""
+    return _hash_messages(0, msgs, dst, msg_off)
+
+
+def hash_to_g2(msgs, dst, msg_off=None):
+    """bn254.HashToG2(msg, dst) for every message, hashing included."""
+    return _hash_messages(1, msgs, dst, msg_off)
+
+
+def hash_to_field(msgs, dst, count=2, msg_off=None):
+    """fp.Hash(msg, dst, count) for every message: [n, count * 32] fp.Elements in gnark's layout (count = 2 or 4)."""
+    if count not in (2, 4):
+        raise ValueError("count must be 2 or 4")
+    return _hash_messages(count, msgs, dst, msg_off)
+
+
 # --------------------------------------------------------------------------------------- fixed-base tables / MSM
 class FixedBase:
     """8-bit window tables of a fixed set of bases kept in HBM (1 MB per G1 base, 2 MB per G2 base): afterwards a term of

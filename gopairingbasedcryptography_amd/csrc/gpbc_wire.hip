@@ -1,8 +1,9 @@
-// libgpbc_bn254.so, unit 4 of 4: gnark wire formats (csrc/wire29.hip.hpp) and the group part of hash to curve
-// (csrc/h2c29.hip.hpp), with their C-ABI entries (include/gpbc_bn254.h).  gfx950 only.
+// libgpbc_bn254.so, unit 4 of 5: gnark wire formats (csrc/wire29.hip.hpp) and hash to curve — hash_to_field
+// (csrc/xmd29.hip.hpp) and the group part (csrc/h2c29.hip.hpp) — with their C-ABI entries (include/gpbc_bn254.h).  gfx950 only.
 #include "gpbc_common.hpp"
 #include "wire29.hip.hpp"
 #include "h2c29.hip.hpp"
+#include "xmd29.hip.hpp"
 
 // ---- wire formats (csrc/wire29.hip.hpp): one element per lane
 GPBC_KERNEL k_g1_encode(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, size_t n, int compressed) {
@@ -49,6 +50,48 @@ GPBC_KERNEL k_g2_map_fields(const uint8_t *__restrict__ u, uint8_t *__restrict__
     if (i >= n) return;
     AffP<F2> r;
     g2_map_fields(r, f2_load(u + i * 128), f2_load(u + i * 128 + 64));
+    g2_store_aff(out + i * GPBC_G2_BYTES, r);
+}
+
+// ---- hash to curve, whole (csrc/xmd29.hip.hpp + h2c29.hip.hpp): one message per lane.  Message i is msgs[off[i], off[i+1]);
+// the offsets are clamped to [0, total] and made monotone, so a malformed device-resident table cannot read outside the buffer.
+__device__ __forceinline__ void msg_range(const uint64_t *__restrict__ off, size_t total, size_t i, uint64_t &lo, uint64_t &len) {
+    uint64_t a = off[i], b = off[i + 1];
+    if (a > total) a = total;
+    if (b > total) b = total;
+    lo = a; len = b > a ? b - a : 0;
+}
+template <int COUNT> GPBC_KERNEL k_hash_to_field(const uint8_t *__restrict__ msgs, const uint64_t *__restrict__ off, size_t total, size_t n, XmdDst dst,
+                                                 uint8_t *__restrict__ out) {
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    uint64_t lo, len;
+    msg_range(off, total, i, lo, len);
+    uint32_t u[COUNT * 12];
+    expand_message_xmd<COUNT * 12 / 8>(u, msgs + lo, len, dst);
+#pragma unroll
+    for (int e = 0; e < COUNT; e++) fe_store(out + (i * COUNT + e) * 32, xmd_field(u, e));
+}
+GPBC_KERNEL k_g1_hash(const uint8_t *__restrict__ msgs, const uint64_t *__restrict__ off, size_t total, size_t n, XmdDst dst, uint8_t *__restrict__ out) {
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    uint64_t lo, len;
+    msg_range(off, total, i, lo, len);
+    uint32_t u[24];
+    expand_message_xmd<3>(u, msgs + lo, len, dst);
+    AffP<Fe> r;
+    g1_map_fields(r, xmd_field(u, 0), xmd_field(u, 1));
+    g1_store_aff(out + i * GPBC_G1_BYTES, r);
+}
+GPBC_KERNEL k_g2_hash(const uint8_t *__restrict__ msgs, const uint64_t *__restrict__ off, size_t total, size_t n, XmdDst dst, uint8_t *__restrict__ out) {
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    uint64_t lo, len;
+    msg_range(off, total, i, lo, len);
+    uint32_t u[48];
+    expand_message_xmd<6>(u, msgs + lo, len, dst);
+    AffP<F2> r;
+    g2_map_fields(r, F2{xmd_field(u, 0), xmd_field(u, 1)}, F2{xmd_field(u, 2), xmd_field(u, 3)});
     g2_store_aff(out + i * GPBC_G2_BYTES, r);
 }
 
@@ -165,5 +208,61 @@ int gpbc_g1_map_to_curve_batch(const void *u, size_t n, void *o) { return map_fi
 int gpbc_g2_map_to_curve_batch(const void *u, size_t n, void *o) { return map_fields_host(true, u, n, o); }
 int gpbc_g1_map_to_curve_batch_dev(const void *u, size_t n, void *o, void *st) { return map_fields_dev(false, u, n, o, st); }
 int gpbc_g2_map_to_curve_batch_dev(const void *u, size_t n, void *o, void *st) { return map_fields_dev(true, u, n, o, st); }
+
+// ----------------------------------------------------------------------------------------------- hash to curve (whole) and hash to field
+// what: 0 = G1 points, 1 = G2 points, 2 / 4 = that many field elements per message
+static size_t hash_out_bytes(int what) { return what == 0 ? GPBC_G1_BYTES : what == 1 ? GPBC_G2_BYTES : (size_t)what * 32; }
+static int hash_dev(int what, const void *d_msgs, const uint64_t *d_off, size_t msgs_bytes, size_t n, const void *dst, size_t dst_len, void *d_out, void *stream) {
+    if (!n) return GPBC_OK;
+    if (!d_off || !d_out || (msgs_bytes && !d_msgs) || (dst_len && !dst)) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    if (dst_len > 255) return fail(GPBC_ERR_INVALID_ARG, "DST longer than 255 bytes: hash it down first (RFC 9380 section 5.3.3)");
+    TRY(bind_device());
+    XmdDst d;
+    memset(&d, 0, sizeof d);
+    memcpy(d.b, dst, dst_len);
+    d.len = (uint32_t)dst_len;
+    hipStream_t st = (hipStream_t)stream;
+    const uint8_t *m = (const uint8_t *)d_msgs;
+    uint8_t *o = (uint8_t *)d_out;
+    switch (what) {
+        case 0: k_g1_hash<<<grid_for(n), BLOCK, 0, st>>>(m, d_off, msgs_bytes, n, d, o); break;
+        case 1: k_g2_hash<<<grid_for(n), BLOCK, 0, st>>>(m, d_off, msgs_bytes, n, d, o); break;
+        case 2: k_hash_to_field<2><<<grid_for(n), BLOCK, 0, st>>>(m, d_off, msgs_bytes, n, d, o); break;
+        case 4: k_hash_to_field<4><<<grid_for(n), BLOCK, 0, st>>>(m, d_off, msgs_bytes, n, d, o); break;
+        default: return fail(GPBC_ERR_INVALID_ARG, "count must be 2 or 4");
+    }
+    return check_launch("k_hash");
+}
+static int hash_one(int what, const uint8_t *msgs, const uint64_t *off, size_t n, const void *dst, size_t dst_len, uint8_t *out) {
+    TRY(bind_device());
+    const uint64_t base = off[0], bytes = off[n] - base;
+    std::vector<uint64_t> rel(n + 1);
+    for (size_t i = 0; i <= n; i++) rel[i] = off[i] - base;
+    DevBuf dM, dOff, dO;
+    TRY(dM.upload(msgs + base, bytes)); TRY(dOff.upload(rel.data(), (n + 1) * sizeof(uint64_t))); TRY(dO.alloc(n * hash_out_bytes(what)));
+    TRY(hash_dev(what, dM.p, (const uint64_t *)dOff.p, bytes, n, dst, dst_len, dO.p, nullptr));
+    TRY(sync_default());
+    return dO.download(out, n * hash_out_bytes(what));
+}
+static int hash_host(int what, const void *msgs, const uint64_t *off, size_t n, const void *dst, size_t dst_len, void *out) {
+    if (!n) return GPBC_OK;
+    if (!off || !out || (dst_len && !dst)) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    for (size_t i = 0; i < n; i++) if (off[i + 1] < off[i]) return fail(GPBC_ERR_INVALID_ARG, "message offsets must not decrease");
+    if (off[n] > off[0] && !msgs) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    const size_t ob = hash_out_bytes(what);
+    return run_sharded(n, 8192, [=](size_t lo, size_t hi) { return hash_one(what, (const uint8_t *)msgs, off + lo, hi - lo, dst, dst_len, (uint8_t *)out + lo * ob); });
+}
+int gpbc_hash_to_g1(const void *m, const uint64_t *off, size_t n, const void *dst, size_t dl, void *o) { return hash_host(0, m, off, n, dst, dl, o); }
+int gpbc_hash_to_g2(const void *m, const uint64_t *off, size_t n, const void *dst, size_t dl, void *o) { return hash_host(1, m, off, n, dst, dl, o); }
+int gpbc_hash_to_field(const void *m, const uint64_t *off, size_t n, const void *dst, size_t dl, int count, void *o) {
+    if (count != 2 && count != 4) return fail(GPBC_ERR_INVALID_ARG, "count must be 2 or 4");
+    return hash_host(count, m, off, n, dst, dl, o);
+}
+int gpbc_hash_to_g1_dev(const void *m, const uint64_t *off, size_t mb, size_t n, const void *dst, size_t dl, void *o, void *st) { return hash_dev(0, m, off, mb, n, dst, dl, o, st); }
+int gpbc_hash_to_g2_dev(const void *m, const uint64_t *off, size_t mb, size_t n, const void *dst, size_t dl, void *o, void *st) { return hash_dev(1, m, off, mb, n, dst, dl, o, st); }
+int gpbc_hash_to_field_dev(const void *m, const uint64_t *off, size_t mb, size_t n, const void *dst, size_t dl, int count, void *o, void *st) {
+    if (count != 2 && count != 4) return fail(GPBC_ERR_INVALID_ARG, "count must be 2 or 4");
+    return hash_dev(count, m, off, mb, n, dst, dl, o, st);
+}
 
 }  // extern "C"

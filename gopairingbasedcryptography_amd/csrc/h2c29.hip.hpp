@@ -5,7 +5,8 @@
 // what gnark-crypto's MapToCurve1 / MapToCurve2 list step by step) with Z = 1 for both curves (the first value RFC 9380
 // Appendix H.1 find_z_svdw accepts; tools/gen_constants.py derives it and c1..c4).  clear_cofactor is Fuentes-Castaneda et al. §6.1 as
 // gnark's G2Jac.ClearCofactor does it:  [x]P + psi([3x]P) + psi^2([x]P) + psi^3(P),  x = the curve parameter u.
-// The message hashing itself (expand_message_xmd with SHA-256, L = 48) is sequential byte work and stays on the host.
+// The message hashing itself (expand_message_xmd with SHA-256, L = 48) is csrc/xmd29.hip.hpp: the k_g1_hash / k_g2_hash kernels
+// run it in the same lane right before this map; the map_fields kernels take field elements a caller hashed itself.
 #ifndef GPBC_H2C29_HIP_HPP
 #define GPBC_H2C29_HIP_HPP
 #include "wire29.hip.hpp"

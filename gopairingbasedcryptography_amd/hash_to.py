@@ -2,10 +2,13 @@
 271-277; hash/hash_from_gt.go:5-8), batched: `bn254.HashToG1(msg, dst)` / `HashToG2(msg, dst)` of gnark-crypto as
 published [EXT, parity unpinned] = RFC 9380 hash_to_curve with
 
-    hash_to_field     expand_message_xmd(SHA-256), L = 48, two field elements        — here, on the host (hashlib):
-                      sequential byte hashing, µs per message
-    map_to_curve      Shallue-van de Woestijne, Z = 1, both elements, then one point addition      } on the GPU
-    clear_cofactor    G2 only: [x]P + psi([3x]P) + psi^2([x]P) + psi^3(P)                           } (bn254.map_to_g1/g2)
+    hash_to_field     expand_message_xmd(SHA-256), L = 48, two field elements                       }
+    map_to_curve      Shallue-van de Woestijne, Z = 1, both elements, then one point addition      } on the GPU, one message
+    clear_cofactor    G2 only: [x]P + psi([3x]P) + psi^2([x]P) + psi^3(P)                           } per lane (bn254.hash_to_g1/g2)
+
+hash_to_g1 / hash_to_g2 below are the product path (csrc/xmd29.hip.hpp + h2c29.hip.hpp).  expand_message_xmd / hash_to_field
+in this file are the hashlib restatement the tests hold against RFC 9380's K.1 vectors and against the device's field
+elements; hash_to_g1_via_host_fields / _g2_ keep the older split (host hashing, device map) for that comparison.
 
 The reference's ToField / BytesToField do not hash at all and are not reproduced here.
 """
@@ -56,14 +59,22 @@ def _mont_rows(elements_per_msg, msgs, dst):
 
 def hash_to_g1(msgs, dst):
     """bn254.HashToG1(msg, dst) for every message: [n, 64] G1Affine rows."""
+    return bn254.hash_to_g1([bytes(m) for m in msgs], dst)
+
+
+def hash_to_g2(msgs, dst):
+    """bn254.HashToG2(msg, dst) for every message: [n, 128] G2Affine rows (E2 element j = base-field elements 2j, 2j+1)."""
+    return bn254.hash_to_g2([bytes(m) for m in msgs], dst)
+
+
+def hash_to_g1_via_host_fields(msgs, dst):
     msgs = [bytes(m) for m in msgs]
     if not msgs:
         return np.zeros((0, bn254.G1_BYTES), dtype=np.uint8)
     return bn254.map_to_g1(_mont_rows(2, msgs, dst))
 
 
-def hash_to_g2(msgs, dst):
-    """bn254.HashToG2(msg, dst) for every message: [n, 128] G2Affine rows (E2 element j = base-field elements 2j, 2j+1)."""
+def hash_to_g2_via_host_fields(msgs, dst):
     msgs = [bytes(m) for m in msgs]
     if not msgs:
         return np.zeros((0, bn254.G2_BYTES), dtype=np.uint8)

@@ -388,40 +388,66 @@ func MarshalGTBatch(gt []bn254.GT) []byte { // GT.Marshal() = GT.Bytes() (hash/h
 	return out
 }
 
-// HashToG1Batch replaces bn254.HashToG1(msg, dst) (hash/hash_to.go:113-119,169-175): gnark's own fp.Hash does the
-// byte hashing (expand_message_xmd), the engine both maps, the addition and — G2 — the cofactor clearing.
+// HashToG1Batch replaces bn254.HashToG1(msg, dst) (hash/hash_to.go:113-119,169-175) for a batch: the engine hashes
+// (expand_message_xmd with SHA-256, reduction to two field elements), maps both, adds.
 func HashToG1Batch(msgs [][]byte, dst []byte) ([]bn254.G1Affine, error) {
-	u := make([]fp.Element, 0, 2*len(msgs))
-	for _, m := range msgs {
-		e, err := fp.Hash(m, dst, 2)
-		if err != nil {
-			return nil, err
-		}
-		u = append(u, e...)
-	}
 	out := make([]bn254.G1Affine, len(msgs))
 	if len(msgs) == 0 {
 		return out, nil
 	}
-	rc := C.gpbc_g1_map_to_curve_batch(unsafe.Pointer(unsafe.SliceData(u)), C.size_t(len(msgs)), unsafe.Pointer(unsafe.SliceData(out)))
+	if len(dst) > 255 {
+		return nil, errors.New("invalid domain size (>255 bytes)") // what gnark's ExpandMsgXmd answers
+	}
+	data, off := flatten(msgs)
+	rc := C.gpbc_hash_to_g1(unsafe.Pointer(unsafe.SliceData(data)), (*C.uint64_t)(unsafe.SliceData(off)), C.size_t(len(msgs)),
+		unsafe.Pointer(unsafe.SliceData(dst)), C.size_t(len(dst)), unsafe.Pointer(unsafe.SliceData(out)))
+	return out, status(rc)
+}
+
+// MapToG1Batch is the group part alone for callers that hold gnark's fp.Hash(msg, dst, 2) output already: u has two
+// elements per point, out[i] = MapToCurve1(u[2i]) + MapToCurve1(u[2i+1]).
+func MapToG1Batch(u []fp.Element) ([]bn254.G1Affine, error) {
+	if len(u)%2 != 0 {
+		return nil, errors.New("two field elements per point")
+	}
+	out := make([]bn254.G1Affine, len(u)/2)
+	if len(out) == 0 {
+		return out, nil
+	}
+	rc := C.gpbc_g1_map_to_curve_batch(unsafe.Pointer(unsafe.SliceData(u)), C.size_t(len(out)), unsafe.Pointer(unsafe.SliceData(out)))
 	return out, status(rc)
 }
 
 // HashToG2Batch replaces bn254.HashToG2 (hash/hash_to.go:204-210,271-277): four base-field elements per message,
-// E2 j = elements 2j (A0) and 2j+1 (A1).
+// E2 j = elements 2j (A0) and 2j+1 (A1); hashing, both maps, addition and cofactor clearing in one call.
 func HashToG2Batch(msgs [][]byte, dst []byte) ([]bn254.G2Affine, error) {
-	u := make([]fp.Element, 0, 4*len(msgs))
-	for _, m := range msgs {
-		e, err := fp.Hash(m, dst, 4)
-		if err != nil {
-			return nil, err
-		}
-		u = append(u, e...)
-	}
 	out := make([]bn254.G2Affine, len(msgs))
 	if len(msgs) == 0 {
 		return out, nil
 	}
-	rc := C.gpbc_g2_map_to_curve_batch(unsafe.Pointer(unsafe.SliceData(u)), C.size_t(len(msgs)), unsafe.Pointer(unsafe.SliceData(out)))
+	if len(dst) > 255 {
+		return nil, errors.New("invalid domain size (>255 bytes)") // what gnark's ExpandMsgXmd answers
+	}
+	data, off := flatten(msgs)
+	rc := C.gpbc_hash_to_g2(unsafe.Pointer(unsafe.SliceData(data)), (*C.uint64_t)(unsafe.SliceData(off)), C.size_t(len(msgs)),
+		unsafe.Pointer(unsafe.SliceData(dst)), C.size_t(len(dst)), unsafe.Pointer(unsafe.SliceData(out)))
 	return out, status(rc)
+}
+
+// flatten lays the messages back to back with their n+1 byte offsets (the layout of gpbc_hash_to_*).
+func flatten(msgs [][]byte) ([]byte, []uint64) {
+	off := make([]uint64, len(msgs)+1)
+	total := 0
+	for i, m := range msgs {
+		total += len(m)
+		off[i+1] = uint64(total)
+	}
+	data := make([]byte, 0, total+1)
+	for _, m := range msgs {
+		data = append(data, m...)
+	}
+	if len(data) == 0 {
+		data = append(data, 0) // SliceData of an empty slice may be nil
+	}
+	return data, off
 }

@@ -236,8 +236,8 @@ int gpbc_gt_unmarshal_batch_dev(const void *d_in, size_t n, void *d_gt_out, uint
 
 /* ---- hash to curve, group part -----------------------------------------------------------------
  * bn254.HashToG1(msg, dst) / HashToG2(msg, dst) (hash/hash_to.go:113-119,169-175,204-210,271-277) after hash_to_field:
- *   u = fp.Hash(msg, dst, 2)  (G2: 2 E2 elements from 4 base-field elements; expand_message_xmd(SHA-256), L = 48 — byte
- *   hashing, stays on the host: the cgo shim calls gnark's fp.Hash, the Python mirror uses hashlib)
+ *   u = fp.Hash(msg, dst, 2)  (G2: 2 E2 elements from 4 base-field elements; expand_message_xmd(SHA-256), L = 48 — computed by
+ *   the caller for these entries; gpbc_hash_to_g1 / _g2 below do it on the device as well)
  *   out = MapToCurve(u[0]) + MapToCurve(u[1])            Shallue-van de Woestijne map, RFC 9380 Appendix F.1, Z = 1
  *   G2: out = ClearCofactor(out)                         [x]P + psi([3x]P) + psi^2([x]P) + psi^3(P)
  * u: n x 2 field elements in gnark's in-memory layout (G1: 2 x 32 B, G2: 2 x 64 B per output point); out: n points. */
@@ -245,6 +245,22 @@ int gpbc_g1_map_to_curve_batch(const void *u, size_t n, void *out);
 int gpbc_g2_map_to_curve_batch(const void *u, size_t n, void *out);
 int gpbc_g1_map_to_curve_batch_dev(const void *d_u, size_t n, void *d_out, void *stream);
 int gpbc_g2_map_to_curve_batch_dev(const void *d_u, size_t n, void *d_out, void *stream);
+
+/* ---- hash to curve, whole ------------------------------------------------------------------------
+ * bn254.HashToG1(msg, dst) / HashToG2(msg, dst) and fp.Hash(msg, dst, count) for n messages in one call
+ * (hash/hash_to.go:113-119 ToG1, :169-175 BytesToG1, :204-210 ToG2, :271-277 BytesToG2; bls01 signing hashes every message,
+ * signature/bls01_signature/bls_signature.go:56-63): expand_message_xmd(SHA-256) and the reduction to field elements run on
+ * the device too (one message per lane, csrc/xmd29.hip.hpp), followed by the map above.
+ * msgs: the messages back to back; msg_off: n + 1 byte offsets (message i = msgs[msg_off[i], msg_off[i+1])); empty messages
+ * are fine.  dst: HOST pointer in every form (it travels in the kernel arguments), at most 255 bytes — hash a longer one down
+ * first as RFC 9380 section 5.3.3 says.  out: n G1 / G2 points, or n x count fp.Elements (count = 2 or 4; gnark's layout).
+ * The _dev forms take device pointers for msgs / msg_off / out plus the size of the msgs buffer (offsets are clamped to it). */
+int gpbc_hash_to_g1(const void *msgs, const uint64_t *msg_off, size_t n, const void *dst, size_t dst_len, void *out);
+int gpbc_hash_to_g2(const void *msgs, const uint64_t *msg_off, size_t n, const void *dst, size_t dst_len, void *out);
+int gpbc_hash_to_field(const void *msgs, const uint64_t *msg_off, size_t n, const void *dst, size_t dst_len, int count, void *out);
+int gpbc_hash_to_g1_dev(const void *d_msgs, const uint64_t *d_msg_off, size_t msgs_bytes, size_t n, const void *dst, size_t dst_len, void *d_out, void *stream);
+int gpbc_hash_to_g2_dev(const void *d_msgs, const uint64_t *d_msg_off, size_t msgs_bytes, size_t n, const void *dst, size_t dst_len, void *d_out, void *stream);
+int gpbc_hash_to_field_dev(const void *d_msgs, const uint64_t *d_msg_off, size_t msgs_bytes, size_t n, const void *dst, size_t dst_len, int count, void *d_out, void *stream);
 
 /* ---- per-kernel timing (measurement, bench.py) ---------------------------------------------------
  * Between begin and end every kernel launch of the pairing / scalar-multiplication entries made on `stream` is bracketed by

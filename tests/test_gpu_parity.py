@@ -626,6 +626,41 @@ def test_hash_to_curve_golden(eng):
     assert hash_to.ToG2("abc").tobytes().hex() == [c for c in g["g2"] if c["msg"] == "abc" and c["dst"] == "string_g2"][0]["point"]
 
 
+def test_hash_to_field_on_device(eng):
+    """expand_message_xmd + reduction on the device (csrc/xmd29.hip.hpp) against the hashlib restatement that the RFC 9380 K.1
+    vectors pin (tests/test_hash_to_curve.py): message lengths around every SHA-256 block and padding boundary, empty and long
+    messages, DSTs of 0 / 1 / 28 / 255 bytes and an oversize one, both element counts; host and device buffers; and the whole
+    hash-to-curve against host hashing + device map."""
+    import torch
+    from gopairingbasedcryptography_amd import hash_to
+    rng = np.random.default_rng(2380)
+    lens = [0, 1, 2, 3, 4, 5, 31, 32, 33, 50, 51, 52, 53, 54, 55, 56, 57, 63, 64, 65, 100, 114, 115, 116, 119, 120, 127, 128, 129, 255, 256, 1000, 4097]
+    msgs = [rng.bytes(n) for n in lens] + [b"abc", b"", b"abcdef0123456789"]
+    mont = lambda v: (v * (1 << 256) % hash_to.P_MOD).to_bytes(32, "little")
+    for dst in (b"", b"d", hash_to.DST_STRING_G1, b"Q" * 255, b"R" * 300):
+        for count in (2, 4):
+            want = np.frombuffer(b"".join(mont(v) for m in msgs for v in hash_to.hash_to_field(m, dst, count)), dtype=np.uint8).reshape(len(msgs), count * 32)
+            assert (eng.hash_to_field(msgs, dst, count) == want).all(), (len(dst), count)
+        assert (eng.hash_to_g1(msgs, dst) == hash_to.hash_to_g1_via_host_fields(msgs, dst)).all()
+    assert (eng.hash_to_g2(msgs, hash_to.DST_BYTES_G2) == hash_to.hash_to_g2_via_host_fields(msgs, hash_to.DST_BYTES_G2)).all()
+    # device-resident messages and offsets; a table that points outside the buffer is clamped (no fault), not trusted
+    data = torch.from_numpy(np.frombuffer(b"".join(msgs), dtype=np.uint8).copy()).cuda()
+    off = torch.tensor(np.concatenate([[0], np.cumsum([len(m) for m in msgs])]), dtype=torch.int64).cuda()
+    want = eng.hash_to_field(msgs, hash_to.DST_BYTES_G1, 2)
+    assert (eng.hash_to_field(data, hash_to.DST_BYTES_G1, 2, msg_off=off).cpu().numpy() == want).all()
+    assert (eng.hash_to_g1(data, hash_to.DST_BYTES_G1, msg_off=off).cpu().numpy() == eng.hash_to_g1(msgs, hash_to.DST_BYTES_G1)).all()
+    bad = off.clone()
+    bad[-1] = 1 << 40
+    got = eng.hash_to_field(data, hash_to.DST_BYTES_G1, 2, msg_off=bad).cpu().numpy()
+    assert (got[:-1] == want[:-1]).all()                       # the last message was cut at the end of the buffer: same bytes here
+    assert (got[-1] == want[-1]).all()
+    with pytest.raises(ValueError):
+        eng.hash_to_field(np.frombuffer(b"abc", dtype=np.uint8), b"d", 2, msg_off=np.array([0, 5], dtype=np.uint64))
+    with pytest.raises(ValueError):
+        eng.hash_to_field([b"abc"], b"d", 3)
+    assert eng.hash_to_g1([], b"d").shape == (0, 64)
+
+
 def test_hash_to_curve_large_batch_properties(eng):
     """Size-independent properties at 2^13 messages: every point passes the curve / subgroup checks of the independent
     unmarshal kernels, the map is deterministic, and BLS sign / verify closes over hashed message points:

@@ -23,6 +23,7 @@ using namespace gpbc;
 // One batch element per lane.  Inputs/outputs are gnark structs (Montgomery R = 2^256, canonical); each kernel
 // converts to the internal 9 x 29-bit signed-limb form on load and back to canonical bytes on store.
 constexpr int BLOCK = 64;
+static_assert(BLOCK == 64, "one wave per workgroup: the LDS slots of the F2 leaf (tower29.hip.hpp) are indexed by the lane number");
 #ifndef GPBC_WAVES_PER_SIMD
 #define GPBC_WAVES_PER_SIMD 2
 #endif

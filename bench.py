@@ -125,6 +125,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = "RANK" in os.environ                      # launched by torch.distributed.run (any world size)
+    # Rehearsal of the N > 1 control flow on a ONE-GPU box (GPBC_BENCH_REHEARSAL=1): every rank uses device 0, torch.distributed
+    # runs on gloo and the library's RCCL communicator is skipped (RCCL refuses two ranks on one device), so the legs that need
+    # the all-gather report an error entry.  Never a measurement: the line says so in config.rehearsal.
+    rehearsal = use_dist and os.environ.get("GPBC_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     if use_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -133,7 +139,10 @@ def main():
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            if rehearsal:
+                dist.init_process_group(backend="gloo")
+            else:
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
             dist.barrier()
             torch.cuda.synchronize()
         finally:
@@ -150,8 +159,8 @@ def main():
         dist.barrier()
     bn254.init(local_rank)
     lib = _lib.load()
-    comm_error = None
-    if use_dist:
+    comm_error = "rehearsal on one GPU: library communicator skipped" if rehearsal else None
+    if use_dist and not rehearsal:
         # the library's own RCCL communicator over the same ranks (the all-gather of partial sums / GT rows)
         sys.stdout.flush()
         saved_stdout = os.dup(1)
@@ -248,6 +257,8 @@ def main():
                    "batch_per_gpu": B, "sharding": "independent index ranges per rank, no data-path collective",
                    "arithmetic": "254-bit Montgomery integers as 9 signed 29-bit limbs (int32), 32x32+64-bit MACs into int64 columns"},
     }
+    if rehearsal:
+        result["config"]["rehearsal"] = "NOT A MEASUREMENT: %d ranks share one GPU (GPBC_BENCH_REHEARSAL=1), gloo, no library communicator" % world
     # ---- roofline, VALU integer-MAC bound: the single kernel with the largest time per step
     frac = lambda fpmul, t_ms: fpmul * MAC_PER_FP_MUL * B / (t_ms * 1e-3) / 1e12 / PEAK_TMAC_PER_S
     for k, v in kern.items():

@@ -487,11 +487,16 @@ def main():
                                                       "chunks of 131072 pairs alternate on two streams, a helper thread drains results on a third"}
             del Qh, gh
             kh = wl.bench_scalars("s", rank * B, B)
-            bn254.g1_scalar_mul(Ph, kh)                                   # first call: per-stream table workspaces
-            t1 = time.perf_counter()
-            bn254.g1_scalar_mul(Ph, kh)
-            result["value_pcie_inclusive"]["g1_scalar_mults_per_s"] = B / (time.perf_counter() - t1)
-            del Ph, kh
+            oh = np.zeros((B, 64), dtype=np.uint8)                        # result buffer with its pages touched, as above
+            bn254.g1_scalar_mul(Ph, kh, out=oh)                           # first call: per-stream table workspaces
+            best = None
+            for _ in range(2):
+                t1 = time.perf_counter()
+                bn254.g1_scalar_mul(Ph, kh, out=oh)
+                d = time.perf_counter() - t1
+                best = d if best is None or d < best else best
+            result["value_pcie_inclusive"]["g1_scalar_mults_per_s"] = B / best
+            del Ph, kh, oh
         except Exception as exc:                          # noqa: BLE001
             result["value_pcie_inclusive"] = {"error": repr(exc)}
         # latency of small host-pointer calls (what the reference's one-pairing-at-a-time call sites would see through the shim)

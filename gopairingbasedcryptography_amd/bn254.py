@@ -347,7 +347,10 @@ def _scalar_mul(width, host_fn, dev_fn, bases, scalars, out):
     n, nbase = scalars.size // SCALAR_BYTES, bases.size // width
     if nbase not in (1, n):
         raise ValueError("need one base or one base per scalar")
-    out = np.empty((n, width), dtype=np.uint8)
+    if out is None:
+        out = np.empty((n, width), dtype=np.uint8)
+    elif not (isinstance(out, np.ndarray) and out.dtype == np.uint8 and out.flags["C_CONTIGUOUS"] and out.flags["WRITEABLE"] and out.size == n * width):
+        raise ValueError("out must be a writable contiguous uint8 array of %d bytes" % (n * width))
     _lib.check(host_fn(_ptr(bases), _sz(nbase), _ptr(scalars), _sz(n), _ptr(out)))
     return out
 

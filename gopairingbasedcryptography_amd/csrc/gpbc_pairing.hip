@@ -472,7 +472,7 @@ static int multi_pair_core(const uint8_t *dP, const uint8_t *dQ, const uint64_t 
     // segment — the chip is full with one lane pair per segment.  Chunks are launched in groups of MULTI_GROUP = 65536
     // (131072 lanes = 2048 waves: exactly one full round of two waves per SIMD on 256 CUs — a lane pair here runs for tens
     // of milliseconds, so a partially filled second round would cost as much as a full one); the slot grid of a group,
-    // L x 65536 lines rows, is at most 10 GB.
+    // L x 65536 lines rows (twice that for an odd L, see the loop), is at most 17.4 GB.
     uint64_t max_len = 0;
     for (size_t j = 0; j < k; j++) if (seg_off[j + 1] - seg_off[j] > max_len) max_len = seg_off[j + 1] - seg_off[j];
     uint64_t L = (n_pairs + 131071) / 131072;
@@ -515,8 +515,11 @@ static int multi_pair_core(const uint8_t *dP, const uint8_t *dQ, const uint64_t 
         HIP_TRY(hipMemcpyAsync(dChunkOff, chunk_off.data(), co_bytes, hipMemcpyHostToDevice, st));   // the vectors outlive the
         HIP_TRY(hipMemcpyAsync(dSegChunk, seg_chunk.data(), sc_bytes, hipMemcpyHostToDevice, st));   // synchronisation below
         std::lock_guard<std::mutex> seq(g_ws_seq_mu);
-        for (size_t cb = 0; cb < n_chunks; cb += MULTI_GROUP) {
-            const size_t g = n_chunks - cb < MULTI_GROUP ? n_chunks - cb : MULTI_GROUP;
+        // the line phase runs one lane per pair: with an odd chunk length a group of 65 536 chunks fills an odd number of half
+        // rounds of the chip (3 pairs: 1.5 rounds, i.e. two) — two groups at a time make it whole (3 rounds for 131 072 chunks)
+        const size_t group = MULTI_GROUP * ((L & 1) && L > 1 ? 2 : 1);
+        for (size_t cb = 0; cb < n_chunks; cb += group) {
+            const size_t g = n_chunks - cb < group ? n_chunks - cb : group;
             size_t longest = 0;
             for (size_t c = cb; c < cb + g; c++) { size_t len = (size_t)(chunk_off[c + 1] - chunk_off[c]); if (len > longest) longest = len; }
             const size_t n_slots = longest * g;

@@ -66,4 +66,31 @@ assert ok.all() and (back == R2).all(), "G2 wire round trip"
 back, ok = bn254.g1_unmarshal(bn254.g1_marshal(R1, compressed=True), elem_bytes=32)
 assert ok.all() and (back == R1).all(), "G1 wire round trip"
 print("GT ops, fixed-base MSM, wire round trips ok  (%.1f s)" % (time.time() - t0), flush=True)
+t0 = time.time()
+from gopairingbasedcryptography_amd import _lib, hash_to  # noqa: E402
+lib = _lib.load()
+try:
+    for trial in range(12):                                   # fixed-Q multi-pairing: random list lengths, segment counts and chunk lengths
+        mq, kq = int(rng.integers(1, 90)), int(rng.integers(1, 40))
+        Qs = Q[rng.integers(0, n, size=mq)].copy()
+        Ps = P[rng.integers(0, n, size=mq * kq)].copy()
+        Qs[rng.integers(0, mq)] = 0 if trial % 3 == 0 else Qs[rng.integers(0, mq)]
+        Ps[rng.integers(0, mq * kq)] = 0
+        _lib.check(lib.gpbc_set_multi_pair_chunk(int(rng.integers(0, 65))))
+        want = oracle_lib.multi_pair(Ps, np.tile(Qs, (kq, 1)), np.arange(0, mq * kq + 1, mq).astype(np.uint64), threads=threads)
+        assert (bn254.multi_pair_fixed_q(Ps, Qs) == want).all(), ("fixed-Q multi-pairing", mq, kq)
+finally:
+    lib.gpbc_set_multi_pair_chunk(0)
+print("fixed-Q multi-pairings ok  (%.1f s)" % (time.time() - t0), flush=True)
+t0 = time.time()
+msgs = [rng.bytes(int(rng.integers(0, 300))) for _ in range(4096)]
+mont = lambda v: (v * (1 << 256) % hash_to.P_MOD).to_bytes(32, "little")
+for dst in (b"soak", rng.bytes(255)):
+    want = np.frombuffer(b"".join(mont(v) for m_ in msgs for v in hash_to.hash_to_field(m_, dst, 4)), dtype=np.uint8).reshape(len(msgs), 128)
+    assert (bn254.hash_to_field(msgs, dst, 4) == want).all(), "hash_to_field"
+H1, H2 = bn254.hash_to_g1(msgs, b"soak"), bn254.hash_to_g2(msgs, b"soak")
+assert (H1 == hash_to.hash_to_g1_via_host_fields(msgs, b"soak")).all() and (H2 == hash_to.hash_to_g2_via_host_fields(msgs, b"soak")).all(), "hash to curve"
+back, ok = bn254.g2_unmarshal(bn254.g2_marshal(H2))
+assert ok.all() and (back == H2).all(), "hashed G2 points are in the group"
+print("hash to field / curve ok  (%d messages, %.1f s)" % (len(msgs), time.time() - t0), flush=True)
 print("soak OK")

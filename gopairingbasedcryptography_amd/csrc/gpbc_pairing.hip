@@ -58,6 +58,64 @@ GPBC_KERNEL k_miller_accumulate(const uint8_t *__restrict__ P, const uint8_t *__
     f6_store(f_out + i * GPBC_GT_BYTES + (x.odd ? 192 : 0), h);
 }
 
+// Small batches: both phases in ONE launch, running CONCURRENTLY.  A single pairing is a chain of ~3 M dependent instructions
+// (0.7 M line phase, 1.0 M accumulator, 1.3 M final exponentiation) and a lone wave issues one every 6-8 cycles, so a call of a few
+// pairings is pure latency; the accumulator only ever needs line s after it has consumed line s - 1, so it can start as soon as the
+// first line exists.  Blocks [0, n_line_blocks) are producers (k_miller_lines' body: after every line a lane publishes its count
+// with an agent-scope release store), the blocks behind them consumers (k_miller_accumulate's body: before line s a lane pair waits
+// until the count of its pairing exceeds s, with acquire loads).  Producer blocks have the lower indices and the grid is far
+// smaller than the chip (n <= PIPELINED_MAX_PAIRS: at most 512 + 1024 of the 2048 resident waves), so every producer is resident
+// before any consumer waits.  The wait is bounded all the same: a lane pair that has spun PIPELINED_SPIN_LIMIT times computes its
+// own lines (same values into the same slots) and goes on — every wave finishes whatever the dispatch order.
+constexpr size_t PIPELINED_MAX_PAIRS = 32768;
+constexpr uint32_t PIPELINED_SPIN_LIMIT = 1u << 22;
+GPBC_KERNEL k_miller_pipelined(const uint8_t *__restrict__ P, const uint8_t *__restrict__ Q, int32_t *lines, uint32_t *progress,
+                               uint8_t *__restrict__ f_out, size_t n, size_t stride, unsigned n_line_blocks) {
+    if (blockIdx.x < n_line_blocks) {
+        size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+        if (i >= n) return;
+        const uint8_t *p = P + i * GPBC_G1_BYTES, *q = Q + i * GPBC_G2_BYTES;
+        if (g1_bytes_inf(p) || g2_bytes_inf(q)) return;      // the consumer checks for itself and does not wait
+        G1A a{fe_load(p), fe_load(p + 32)};
+        G2A b{f2_load(q), f2_load(q + 64)};
+        int step = 0;
+        miller_lines(a, b, [&](const LineS &l) {
+            line_store(lines, stride, i, step++, l);
+            __hip_atomic_store(progress + i, (uint32_t)step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        });
+        return;
+    }
+    size_t lane = (size_t)(blockIdx.x - n_line_blocks) * BLOCK + threadIdx.x;
+    size_t i = lane >> 1;
+    if (i >= n) return;
+    PairDpp x{(bool)(lane & 1)};
+    const uint8_t *p = P + i * GPBC_G1_BYTES, *q = Q + i * GPBC_G2_BYTES;
+    F6 h;
+    if (g1_bytes_inf(p) || g2_bytes_inf(q)) h = f12p_one(x);
+    else {
+        int step = 0;
+        bool own_lines = false;
+        h = miller_accumulate_pair(x, [&]() -> LineS {
+            if (!own_lines) {
+                uint32_t spins = 0;
+                while (__hip_atomic_load(progress + i, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) <= (uint32_t)step) {
+                    __builtin_amdgcn_s_sleep(16);
+                    if (++spins > PIPELINED_SPIN_LIMIT) { own_lines = true; break; }
+                }
+                if (own_lines) {                              // never seen in practice; both lanes of the pair write the same values
+                    G1A a{fe_load(p), fe_load(p + 32)};
+                    G2A b{f2_load(q), f2_load(q + 64)};
+                    int s2 = 0;
+                    miller_lines(a, b, [&](const LineS &l) { line_store(lines, stride, i, s2++, l); });
+                    __threadfence();
+                }
+            }
+            return line_load(lines, stride, i, step++);
+        });
+    }
+    f6_store(f_out + i * GPBC_GT_BYTES + (x.odd ? 192 : 0), h);
+}
+
 // Multi-pairing form of the two phases (host entry gpbc_multi_pair / gpbc_pairing_check): the pairs of a segment are cut
 // into chunks of at most MULTI_CHUNK pairs, one lane pair accumulates a whole chunk with SHARED squarings
 // (miller_accumulate_multi), and the lines workspace is laid out by slot = i * n_chunks + c (pair i of chunk c) so that
@@ -281,12 +339,29 @@ GPBC_KERNEL k_gt_binary(const uint8_t *__restrict__ a, const uint8_t *__restrict
 
 extern "C" {
 
+// test / measurement knob: 0 = always the two-kernel form
+static std::atomic<int> g_pipelined{1};
+int gpbc_set_pipelined_miller(int on) { g_pipelined.store(on ? 1 : 0); return GPBC_OK; }
 int gpbc_miller_loop_dev(const void *dP, const void *dQ, size_t n, void *d_f_out, void *stream) {
     if (!n) return GPBC_OK;
     if (!dP || !dQ || !d_f_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
     TRY(bind_device());
     hipStream_t st = (hipStream_t)stream;
     size_t chunk = n < MILLER_CHUNK ? n : MILLER_CHUNK;
+    if (n <= PIPELINED_MAX_PAIRS && g_pipelined.load()) {
+        Scratch flags;                                            // level 2: callers may hold levels 0 and 1 on this stream
+        TRY(flags.open(st, 2, n * sizeof(uint32_t)));
+        uint32_t *progress = flags.take<uint32_t>(n * sizeof(uint32_t));
+        std::lock_guard<std::mutex> seq(g_ws_seq_mu);
+        int32_t *lines = nullptr;
+        TRY(lines_workspace(st, n, &lines));
+        HIP_TRY(hipMemsetAsync(progress, 0, n * sizeof(uint32_t), st));
+        const unsigned n_line_blocks = grid_for(n);
+        k_miller_pipelined<<<n_line_blocks + grid_for(2 * n), BLOCK, 0, st>>>((const uint8_t *)dP, (const uint8_t *)dQ, lines, progress, (uint8_t *)d_f_out, n, n, n_line_blocks);
+        TRY(check_launch("k_miller_pipelined"));
+        profile_mark("k_miller_pipelined", st);
+        return GPBC_OK;
+    }
     std::lock_guard<std::mutex> seq(g_ws_seq_mu);
     int32_t *lines = nullptr;
     TRY(lines_workspace(st, chunk, &lines));

@@ -134,6 +134,35 @@ def test_multi_pair_shared_squarings_chunks(eng, oracle, synth):
     assert ok.tolist() == [0, 0, 0, 0, 0, 1, 0, 0]          # only the empty product is one
 
 
+def test_pipelined_small_batches_match_the_two_kernel_form(eng, oracle):
+    """Batches of up to 32 768 pairings run the line phase and the accumulator concurrently in one launch
+    (k_miller_pipelined: producer blocks publish their line counts, consumer lane pairs wait for them).  Same bytes as the
+    two-kernel form (gpbc_set_pipelined_miller(0)) and as the oracle, for sizes around the block edges, with infinities,
+    host and device buffers, Miller values and full pairings."""
+    import torch
+    from gopairingbasedcryptography_amd import _lib
+    lib = _lib.load()
+    g1, g2 = eng.generators()
+    n = 32768
+    P = eng.g1_scalar_mul(g1, scalars("pipe-P", n))
+    Q = eng.g2_scalar_mul(g2, scalars("pipe-Q", n))
+    P[5] = 0
+    Q[64] = 0
+    P[n - 1] = 0
+    dP, dQ = torch.from_numpy(P).cuda(), torch.from_numpy(Q).cuda()
+    try:
+        for m in (1, 2, 31, 32, 33, 63, 64, 65, 1000, n):
+            _lib.check(lib.gpbc_set_pipelined_miller(1))
+            f1, e1 = eng.miller_loop(P[:m], Q[:m]), eng.pair_batch(dP[:m].contiguous(), dQ[:m].contiguous()).cpu().numpy()
+            _lib.check(lib.gpbc_set_pipelined_miller(0))
+            f0, e0 = eng.miller_loop(P[:m], Q[:m]), eng.pair_batch(P[:m], Q[:m])
+            assert (f1 == f0).all() and (e1 == e0).all(), m
+    finally:
+        lib.gpbc_set_pipelined_miller(1)
+    assert (e1[:200] == oracle.pair_batch(P[:200], Q[:200], threads=8)).all()
+    assert e1[5].tobytes() == o.gt_to_bytes(o.F12_ONE) and e1[64].tobytes() == o.gt_to_bytes(o.F12_ONE)
+
+
 def test_multi_pair_fixed_q(eng, oracle, synth):
     """One shared G2 list against k segments of G1 points (precomputed lines): equal to multi_pair on the replicated list
     and to the oracle, for forced chunk lengths and the automatic one; infinities on both sides; device path."""

@@ -70,7 +70,7 @@ GPBC_KERNEL k_miller_accumulate(const uint8_t *__restrict__ P, const uint8_t *__
 constexpr size_t PIPELINED_MAX_PAIRS = 32768;
 constexpr uint32_t PIPELINED_SPIN_LIMIT = 1u << 22;
 GPBC_KERNEL k_miller_pipelined(const uint8_t *__restrict__ P, const uint8_t *__restrict__ Q, int32_t *lines, uint32_t *progress,
-                               uint8_t *__restrict__ f_out, size_t n, size_t stride, unsigned n_line_blocks) {
+                               uint8_t *__restrict__ f_out, size_t n, size_t stride, unsigned n_line_blocks, uint32_t spin_limit) {
     if (blockIdx.x < n_line_blocks) {
         size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
         if (i >= n) return;
@@ -100,7 +100,7 @@ GPBC_KERNEL k_miller_pipelined(const uint8_t *__restrict__ P, const uint8_t *__r
                 uint32_t spins = 0;
                 while (__hip_atomic_load(progress + i, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) <= (uint32_t)step) {
                     __builtin_amdgcn_s_sleep(16);
-                    if (++spins > PIPELINED_SPIN_LIMIT) { own_lines = true; break; }
+                    if (++spins > spin_limit) { own_lines = true; break; }
                 }
                 if (own_lines) {                              // never seen in practice; both lanes of the pair write the same values
                     G1A a{fe_load(p), fe_load(p + 32)};
@@ -339,9 +339,10 @@ GPBC_KERNEL k_gt_binary(const uint8_t *__restrict__ a, const uint8_t *__restrict
 
 extern "C" {
 
-// test / measurement knob: 0 = always the two-kernel form
+// test / measurement knob: 0 = always the two-kernel form, 2 = pipelined with a spin limit of zero (every consumer that finds its
+// line missing computes its own: the fallback path, which a healthy run never takes)
 static std::atomic<int> g_pipelined{1};
-int gpbc_set_pipelined_miller(int on) { g_pipelined.store(on ? 1 : 0); return GPBC_OK; }
+int gpbc_set_pipelined_miller(int on) { g_pipelined.store(on == 2 ? 2 : on ? 1 : 0); return GPBC_OK; }
 int gpbc_miller_loop_dev(const void *dP, const void *dQ, size_t n, void *d_f_out, void *stream) {
     if (!n) return GPBC_OK;
     if (!dP || !dQ || !d_f_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
@@ -357,7 +358,8 @@ int gpbc_miller_loop_dev(const void *dP, const void *dQ, size_t n, void *d_f_out
         TRY(lines_workspace(st, n, &lines));
         HIP_TRY(hipMemsetAsync(progress, 0, n * sizeof(uint32_t), st));
         const unsigned n_line_blocks = grid_for(n);
-        k_miller_pipelined<<<n_line_blocks + grid_for(2 * n), BLOCK, 0, st>>>((const uint8_t *)dP, (const uint8_t *)dQ, lines, progress, (uint8_t *)d_f_out, n, n, n_line_blocks);
+        k_miller_pipelined<<<n_line_blocks + grid_for(2 * n), BLOCK, 0, st>>>((const uint8_t *)dP, (const uint8_t *)dQ, lines, progress, (uint8_t *)d_f_out, n, n, n_line_blocks,
+                                                                                       g_pipelined.load() == 2 ? 0u : PIPELINED_SPIN_LIMIT);
         TRY(check_launch("k_miller_pipelined"));
         profile_mark("k_miller_pipelined", st);
         return GPBC_OK;

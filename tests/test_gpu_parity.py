@@ -152,11 +152,12 @@ def test_pipelined_small_batches_match_the_two_kernel_form(eng, oracle):
     dP, dQ = torch.from_numpy(P).cuda(), torch.from_numpy(Q).cuda()
     try:
         for m in (1, 2, 31, 32, 33, 63, 64, 65, 1000, n):
-            _lib.check(lib.gpbc_set_pipelined_miller(1))
-            f1, e1 = eng.miller_loop(P[:m], Q[:m]), eng.pair_batch(dP[:m].contiguous(), dQ[:m].contiguous()).cpu().numpy()
             _lib.check(lib.gpbc_set_pipelined_miller(0))
             f0, e0 = eng.miller_loop(P[:m], Q[:m]), eng.pair_batch(P[:m], Q[:m])
-            assert (f1 == f0).all() and (e1 == e0).all(), m
+            for mode in (2, 1):                       # 2: no waiting, consumers compute missing lines themselves (the fallback path)
+                _lib.check(lib.gpbc_set_pipelined_miller(mode))
+                f1, e1 = eng.miller_loop(P[:m], Q[:m]), eng.pair_batch(dP[:m].contiguous(), dQ[:m].contiguous()).cpu().numpy()
+                assert (f1 == f0).all() and (e1 == e0).all(), (m, mode)
     finally:
         lib.gpbc_set_pipelined_miller(1)
     assert (e1[:200] == oracle.pair_batch(P[:200], Q[:200], threads=8)).all()

@@ -151,6 +151,30 @@ inline bool PairingCheck(const std::vector<G1Affine> &P, const std::vector<G2Aff
     check(gpbc_pairing_check(P.data(), Q.data(), seg, 1, &ok));
     return ok == 1;
 }
+// bn254.HashToG1(msg, dst) / HashToG2(msg, dst) (hash/hash_to.go:113-119,169-175,204-210,271-277; the BLS scheme hashes every
+// message: signature/bls01_signature/bls_signature.go:56-63), hashing included; gnark errors on a DST longer than 255 bytes
+inline std::vector<G1Affine> HashToG1Batch(const std::vector<std::string> &msgs, const std::string &dst) {
+    if (dst.size() > 255) throw std::invalid_argument("invalid domain size (>255 bytes)");
+    std::vector<G1Affine> out(msgs.size());
+    std::string data;
+    std::vector<uint64_t> off(msgs.size() + 1, 0);
+    for (size_t i = 0; i < msgs.size(); i++) { data += msgs[i]; off[i + 1] = data.size(); }
+    if (data.empty()) data.push_back('\0');
+    check(gpbc_hash_to_g1(data.data(), off.data(), msgs.size(), dst.data(), dst.size(), out.data()));
+    return out;
+}
+inline std::vector<G2Affine> HashToG2Batch(const std::vector<std::string> &msgs, const std::string &dst) {
+    if (dst.size() > 255) throw std::invalid_argument("invalid domain size (>255 bytes)");
+    std::vector<G2Affine> out(msgs.size());
+    std::string data;
+    std::vector<uint64_t> off(msgs.size() + 1, 0);
+    for (size_t i = 0; i < msgs.size(); i++) { data += msgs[i]; off[i + 1] = data.size(); }
+    if (data.empty()) data.push_back('\0');
+    check(gpbc_hash_to_g2(data.data(), off.data(), msgs.size(), dst.data(), dst.size(), out.data()));
+    return out;
+}
+inline G1Affine HashToG1(const std::string &msg, const std::string &dst) { return HashToG1Batch({msg}, dst)[0]; }
+inline G2Affine HashToG2(const std::string &msg, const std::string &dst) { return HashToG2Batch({msg}, dst)[0]; }
 // batched forms the engine adds
 inline std::vector<GT> PairBatch(const std::vector<G1Affine> &P, const std::vector<G2Affine> &Q) {
     if (P.empty() || P.size() != Q.size()) throw std::invalid_argument("invalid inputs sizes");

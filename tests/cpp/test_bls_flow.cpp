@@ -1,7 +1,7 @@
 // Mirrors the reference's BLS tests (signature/bls01_signature/bls_signature_test.go:8-72) on the C++ host mirror
 // of the gnark surface (include/gpbc_bn254.hpp): key generation, sign, verify through PairingCheck on the GPU,
-// plus the wrong-message / wrong-key negatives.  Hash-to-G2 is out of scope: the message point is
-// H = [h(m)]g2 with h(m) a byte-derived scalar, which keeps the sign/verify algebra of bls_signature.go:58-89.
+// plus the wrong-message / wrong-key negatives.  The message point is the real hash, bn254.HashToG2(msg, dst) with the
+// reference's DST (hash/hash_to.go:204-210), computed on the device; bls_signature.go:58-89.
 #include <cstdio>
 #include <string>
 #include "gpbc_bn254.hpp"
@@ -25,7 +25,7 @@ static KeyPair KeyGenerate(uint64_t seed) {                      // bls_signatur
     kp.pk.ScalarMultiplicationBase(kp.sk);
     return kp;
 }
-static G2Affine HashStandIn(const std::string &m) { G2Affine h; h.ScalarMultiplicationBase(scalar_from(m, 7)); return h; }
+static G2Affine HashStandIn(const std::string &m) { return HashToG2(m, "Hash String To Element In G2"); }
 static G2Affine Sign(const Scalar &sk, const std::string &m) {   // bls_signature.go:58-69
     G2Affine hm = HashStandIn(m), sig;
     sig.ScalarMultiplication(hm, sk);

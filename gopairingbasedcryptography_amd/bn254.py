@@ -63,6 +63,12 @@ def num_devices():
     return int(_lib.load().gpbc_num_devices())
 
 
+def release_workspaces():
+    """Hand the library's grow-only device buffers (workspaces, per-call scratch) back to the driver; they regrow on demand."""
+    _ensure_init()
+    _lib.check(_lib.load().gpbc_release_workspaces())
+
+
 def shutdown():
     global _slots
     _lib.check(_lib.load().gpbc_shutdown())

@@ -291,6 +291,16 @@ int gpbc_set_device(int index) {
 int gpbc_get_device(void) { return g_ndev.load() > 0 ? cur_index() : fail(GPBC_ERR_NO_DEVICE, "gpbc_init() has not bound a HIP device"); }
 int gpbc_set_host_sharding(int on) { g_host_sharding.store(on ? 1 : 0); return GPBC_OK; }
 
+int gpbc_release_workspaces(void) {
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    for (int i = 0; i < g_ndev.load(); i++) {
+        HIP_TRY(hipSetDevice(g_ctx[i].hip));
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    free_workspaces();
+    if (g_ndev.load() > 0) HIP_TRY(hipSetDevice(g_ctx[cur_index() < g_ndev.load() ? cur_index() : 0].hip));
+    return GPBC_OK;
+}
 int gpbc_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_dev_mu);
     {

@@ -66,6 +66,10 @@ int gpbc_set_device(int index);            /* current device of the calling thre
 int gpbc_get_device(void);                 /* its index, <0 before init */
 int gpbc_set_host_sharding(int on);        /* default 1; 0: host-pointer entries stay on the caller's current device */
 int gpbc_shutdown(void);
+/* Returns the library's grow-only device buffers (line / table workspaces and per-call scratch of every (device, stream): up to
+ * several GB after BASELINE-size calls) to the driver; they come back on demand.  Synchronises the bound devices first.  For
+ * long-lived processes that share HBM with other users; calls in flight on other threads must have returned. */
+int gpbc_release_workspaces(void);
 const char *gpbc_last_error(void);         /* thread-local, never NULL */
 int gpbc_device_count(void);               /* number of visible HIP devices, <0 on error */
 int gpbc_abi_version(void);

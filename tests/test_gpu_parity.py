@@ -134,6 +134,21 @@ def test_multi_pair_shared_squarings_chunks(eng, oracle, synth):
     assert ok.tolist() == [0, 0, 0, 0, 0, 1, 0, 0]          # only the empty product is one
 
 
+def test_release_workspaces(eng, synth):
+    """gpbc_release_workspaces hands the grow-only buffers back; the next calls rebuild them and give the same bytes."""
+    import torch
+    P, Q = synth
+    P, Q = P.reshape(-1, 64)[:64], Q.reshape(-1, 128)[:64]
+    dP, dQ = torch.from_numpy(P.copy()).cuda(), torch.from_numpy(Q.copy()).cuda()
+    before = (eng.pair_batch(dP, dQ).cpu().numpy(), eng.multi_pair_fixed_q(P[:48].copy(), Q[:12].copy()), eng.g1_scalar_mul(P, scalars("rel", 64)))
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    eng.release_workspaces()
+    assert torch.cuda.mem_get_info()[0] >= free0
+    after = (eng.pair_batch(dP, dQ).cpu().numpy(), eng.multi_pair_fixed_q(P[:48].copy(), Q[:12].copy()), eng.g1_scalar_mul(P, scalars("rel", 64)))
+    assert all((a == b).all() for a, b in zip(before, after))
+
+
 def test_pipelined_small_batches_match_the_two_kernel_form(eng, oracle):
     """Batches of up to 32 768 pairings run the line phase and the accumulator concurrently in one launch
     (k_miller_pipelined: producer blocks publish their line counts, consumer lane pairs wait for them).  Same bytes as the

@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(BLOCK) k_fp_mul(const uint8_t *__restrict__ a,
 
 extern "C" {
 
-int gpbc_abi_version(void) { return 5; }
+int gpbc_abi_version(void) { return 6; }   // 6: hash-to-curve entries, release_workspaces, pipelined-Miller knob; fixed-Q _dev entry asynchronous
 const char *gpbc_last_error(void) { return g_err; }
 
 int gpbc_device_count(void) {

@@ -64,10 +64,10 @@ GPBC_KERNEL k_miller_accumulate(const uint8_t *__restrict__ P, const uint8_t *__
 // first line exists.  Blocks [0, n_line_blocks) are producers (k_miller_lines' body: after every line a lane publishes its count
 // with an agent-scope release store), the blocks behind them consumers (k_miller_accumulate's body: before line s a lane pair waits
 // until the count of its pairing exceeds s, with acquire loads).  Producer blocks have the lower indices and the grid is far
-// smaller than the chip (n <= PIPELINED_MAX_PAIRS: at most 512 + 1024 of the 2048 resident waves), so every producer is resident
+// smaller than the chip (n <= PIPELINED_MAX_PAIRS: at most 256 + 512 of the 2048 resident waves; at 32 768 pairs the waiting consumers cost the producers more than the overlap gains, profiles/r02_pipelined_sizes.txt), so every producer is resident
 // before any consumer waits.  The wait is bounded all the same: a lane pair that has spun PIPELINED_SPIN_LIMIT times computes its
 // own lines (same values into the same slots) and goes on — every wave finishes whatever the dispatch order.
-constexpr size_t PIPELINED_MAX_PAIRS = 32768;
+constexpr size_t PIPELINED_MAX_PAIRS = 16384;
 constexpr uint32_t PIPELINED_SPIN_LIMIT = 1u << 22;
 GPBC_KERNEL k_miller_pipelined(const uint8_t *__restrict__ P, const uint8_t *__restrict__ Q, int32_t *lines, uint32_t *progress,
                                uint8_t *__restrict__ f_out, size_t n, size_t stride, unsigned n_line_blocks, uint32_t spin_limit) {

@@ -132,7 +132,7 @@ int gpbc_multi_pair_fixed_q_dev(const void *dP, const void *dQ, size_t m, size_t
 /* Tuning / test knob of the multi-pairing paths: pairs per shared-squaring chunk, 1..64 (the general path, whose lines live in a
  * per-slot workspace, caps it at 8; the fixed-Q path takes all of it); 0 (default) = chosen from the batch size. */
 int gpbc_set_multi_pair_chunk(int pairs_per_chunk);
-/* Batches of up to 32 768 pairings run the two phases of the Miller loop concurrently in one launch (the accumulator consumes
+/* Batches of up to 16 384 pairings run the two phases of the Miller loop concurrently in one launch (the accumulator consumes
  * the lines as they are produced: about a third off the latency of a small call).  0 switches to the two-kernel form used for
  * large batches (tests compare the two); default 1.  2 = pipelined with no waiting at all (a consumer that finds its line
  * missing computes its own lines: the bounded-wait fallback, for tests). */

@@ -150,7 +150,7 @@ def test_release_workspaces(eng, synth):
 
 
 def test_pipelined_small_batches_match_the_two_kernel_form(eng, oracle):
-    """Batches of up to 32 768 pairings run the line phase and the accumulator concurrently in one launch
+    """Batches of up to 16 384 pairings run the line phase and the accumulator concurrently in one launch
     (k_miller_pipelined: producer blocks publish their line counts, consumer lane pairs wait for them).  Same bytes as the
     two-kernel form (gpbc_set_pipelined_miller(0)) and as the oracle, for sizes around the block edges, with infinities,
     host and device buffers, Miller values and full pairings."""
@@ -158,7 +158,7 @@ def test_pipelined_small_batches_match_the_two_kernel_form(eng, oracle):
     from gopairingbasedcryptography_amd import _lib
     lib = _lib.load()
     g1, g2 = eng.generators()
-    n = 32768
+    n = 16640                                  # one block of 64 beyond the pipelined limit
     P = eng.g1_scalar_mul(g1, scalars("pipe-P", n))
     Q = eng.g2_scalar_mul(g2, scalars("pipe-Q", n))
     P[5] = 0
@@ -166,7 +166,7 @@ def test_pipelined_small_batches_match_the_two_kernel_form(eng, oracle):
     P[n - 1] = 0
     dP, dQ = torch.from_numpy(P).cuda(), torch.from_numpy(Q).cuda()
     try:
-        for m in (1, 2, 31, 32, 33, 63, 64, 65, 1000, n):
+        for m in (1, 2, 31, 32, 33, 63, 64, 65, 1000, 16384, n):
             _lib.check(lib.gpbc_set_pipelined_miller(0))
             f0, e0 = eng.miller_loop(P[:m], Q[:m]), eng.pair_batch(P[:m], Q[:m])
             for mode in (2, 1):                       # 2: no waiting, consumers compute missing lines themselves (the fallback path)

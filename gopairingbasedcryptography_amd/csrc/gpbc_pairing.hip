@@ -29,6 +29,31 @@ __device__ __forceinline__ LineS line_load(const int32_t *__restrict__ buf, size
     return l;
 }
 
+// The accumulator's line stream through LDS, loaded by the DMA path (global_load_lds_dword: HBM -> LDS without a destination
+// register): line s + 1 is requested as soon as line s has been read out of the stage, so its HBM latency passes behind the sparse
+// product and the next squaring instead of in front of the product (the compiler cannot hoist 54 register loads above six leaf
+// calls; an LDS stage costs no registers).  Each lane of a pair requests half of the 54 words — the even lane words 0..26, the odd
+// lane 27..53, one 256-byte LDS row per request — and both read all of them back.  -DGPBC_LINES_BY_REGISTER_LOADS is the previous
+// form (A/B runs).
+#ifndef GPBC_LINES_BY_REGISTER_LOADS
+__shared__ int32_t g_line_stage[27][BLOCK];
+__device__ __forceinline__ void line_request(const int32_t *__restrict__ buf, size_t stride, size_t lane, int step, bool odd) {
+    const int32_t *b = buf + ((size_t)step * LINE_WORDS + (odd ? 27 : 0)) * stride + lane;
+#pragma unroll
+    for (int r = 0; r < 27; r++) __builtin_amdgcn_global_load_lds(b + (size_t)r * stride, &g_line_stage[r][0], 4, 0, 0);
+}
+__device__ __forceinline__ LineS line_from_stage() {
+    __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0): the requested words have landed
+    const unsigned e = threadIdx.x & ~1u;
+    LineS l;
+    Fe *fe[6] = {&l.c0.a0, &l.c0.a1, &l.c3.a0, &l.c3.a1, &l.c4.a0, &l.c4.a1};
+#pragma unroll
+    for (int w = 0; w < LINE_WORDS; w++) fe[w / NL]->v[w % NL] = g_line_stage[w < 27 ? w : w - 27][e + (w < 27 ? 0 : 1)];
+    __builtin_amdgcn_s_waitcnt(0xC07F);                          // lgkmcnt(0): read out before the next request may overwrite the stage
+    return l;
+}
+#endif
+
 GPBC_KERNEL k_miller_lines(const uint8_t *__restrict__ P, const uint8_t *__restrict__ Q, int32_t *__restrict__ lines, size_t n, size_t stride) {
     size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -53,7 +78,16 @@ GPBC_KERNEL k_miller_accumulate(const uint8_t *__restrict__ P, const uint8_t *__
     if (g1_bytes_inf(p) || g2_bytes_inf(q)) h = f12p_one(x);
     else {
         int step = 0;
+#ifndef GPBC_LINES_BY_REGISTER_LOADS
+        line_request(lines, stride, i, 0, x.odd);
+        h = miller_accumulate_pair(x, [&]() -> LineS {
+            LineS l = line_from_stage();
+            if (++step < MILLER_LINES) line_request(lines, stride, i, step, x.odd);
+            return l;
+        });
+#else
         h = miller_accumulate_pair(x, [&]() -> LineS { return line_load(lines, stride, i, step++); });
+#endif
     }
     f6_store(f_out + i * GPBC_GT_BYTES + (x.odd ? 192 : 0), h);
 }

@@ -268,14 +268,17 @@ GPBC_KERNEL k_miller_accumulate_fixed_q(const int32_t *__restrict__ Pint, const 
     if (n == 0) h = f12p_one(x);
     else h = miller_accumulate_multi_34(x, n, [&](int p, int li) -> Line34 {
         const size_t i = (size_t)vi[p];
-        Line34 r = line34_load(q34, m, i, li);                    // (r1 / r0, r2 / r0) of Q_i: the same address for the whole wave
-        const int32_t *pp = Pint + (j * m + i) * 20;
-        // the line at P: c3 = (r1 / r0) (xP / yP), c4 = (r2 / r0) / yP.  Both lanes of the pair need both; each computes ONE of the
-        // two Fp x Fp2 products (even lane c3, odd lane c4) and they swap
+        // the line at P: c3 = (r1 / r0) (xP / yP), c4 = (r2 / r0) / yP.  Both lanes of the pair need both; each loads ONE coefficient
+        // of the table row (the same address for all even / all odd lanes of the wave) and ONE coordinate, computes its Fp x Fp2
+        // product (even lane c3, odd lane c4), and they swap the products.  (The LDS stage of k_miller_accumulate was tried here as
+        // well and is 1 % SLOWER: these loads hit L2 — the table row is shared by the whole grid — and have little latency to hide.)
+        const int32_t *lb = q34 + ((size_t)li * LINE34_WORDS + (x.odd ? 2 * NL : 0)) * m + i;
+        const int32_t *pp = Pint + (j * m + i) * 20 + (x.odd ? NL : 0);                 // odd: 1 / yP, even: xP / yP
+        F2 coef;
         Fe pc;
 #pragma unroll
-        for (int w = 0; w < NL; w++) pc.v[w] = x.odd ? pp[NL + w] : pp[w];            // odd: 1 / yP, even: xP / yP
-        const F2 mine = f2_mul_fe(f2_sel(x.odd, r.c4, r.c3), pc), other = x.swap(mine);
+        for (int w = 0; w < NL; w++) { coef.a0.v[w] = lb[(size_t)w * m]; coef.a1.v[w] = lb[(size_t)(NL + w) * m]; pc.v[w] = pp[w]; }
+        const F2 mine = f2_mul_fe(coef, pc), other = x.swap(mine);
         return Line34{f2_sel(x.odd, other, mine), f2_sel(x.odd, mine, other)};
     });
     f6_store(f_out + (j * n_c + c) * GPBC_GT_BYTES + (x.odd ? 192 : 0), h);     // segment-major: chunks of a segment are adjacent

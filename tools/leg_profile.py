@@ -28,6 +28,6 @@ inst = wl.bsw07_instance(bn254, "256of256", n, dev)
 folded = bsw07.fold_key(bn254, bsw07.decrypt_plan(inst["tree"], inst["attrs"]), inst["dj"], inst["dj_prime"])
 profiled("BSW07 decrypt, %d ciphertexts x 513 pairs" % n, lambda: bsw07.decrypt_batch_arrays(bn254, folded, inst["D"], inst["c_tilde"], inst["c"], inst["cy"], inst["cy_prime"]))
 del inst
-m = 1 << 17
+m = 1 << 16
 a = wl.afp25_instance(bn254, 256, m, dev)
 profiled("AFP25 decrypt, %d items x 3 pairs" % m, lambda: afp25.decrypt_batch_arrays(bn254, a["D"], a["pi"], a["sk"], a["C1"], a["C2"]))

@@ -225,16 +225,6 @@ GPBC_KERNEL k_q_lines_scale(const int32_t *__restrict__ qlines, int32_t *__restr
 #pragma unroll
         for (int w = 0; w < NL; w++) o[(size_t)(e * NL + w) * m] = fe[e]->v[w];
 }
-__device__ __forceinline__ Line34 line34_load(const int32_t *__restrict__ buf, size_t stride, size_t lane, int step) {
-    const int32_t *b = buf + (size_t)step * LINE34_WORDS * stride + lane;
-    Line34 l;
-    Fe *fe[4] = {&l.c3.a0, &l.c3.a1, &l.c4.a0, &l.c4.a1};
-#pragma unroll
-    for (int e = 0; e < 4; e++)
-#pragma unroll
-        for (int w = 0; w < NL; w++) fe[e]->v[w] = b[(size_t)(e * NL + w) * stride];
-    return l;
-}
 // The evaluation point of such a line: (x / y, 1 / y) in internal limbs (the division by yP is the Fp factor that makes c0 = 1).
 // 20 int32 per point: x/y (9), 1/y (9), infinity flag, pad.  One lane converts LINE_POINT_GROUP consecutive points with ONE Fp
 // inversion (fe_batch_inverse); a zero y — infinity, or a point outside the group — does not spoil its neighbours.

@@ -74,7 +74,7 @@ GPBC_INLINE F2 f2_from_vec(const i32x18 &v) {
 }
 // An F2 product has 36 operand limbs and the calling convention 31 argument VGPRs (v31 carries the work-item id).  The last
 // five used to travel through the stack, i.e. private memory — and the PMC counters show that on this machine every
-// private-memory access of these kernels reaches HBM (profiles/r02_final_pmc_traffic.json: k_final_exp wrote 17 KB and fetched
+// private-memory access of these kernels reaches HBM (profiles/r02_final5_pmc_traffic.json: k_final_exp wrote 17 KB and fetched
 // 20 KB per lane, its dynamic count of scratch stores and loads times four bytes): ten HBM transactions per product, more than
 // half of the kernel's traffic.  They go through LDS instead: a 16-byte and a 4-byte slot per lane of the (64-thread) workgroup,
 // written by the caller right before the call and read first thing by the leaf, in order on the wave's LDS queue.  The slot is

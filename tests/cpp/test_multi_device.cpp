@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstring>
 #include <thread>
+#include <string>
 #include <vector>
 #include "gpbc_bn254.hpp"
 
@@ -101,6 +102,23 @@ int main() {
         check(gpbc_g2_unmarshal_batch(w.data(), 64, N, back.data(), okw.data()));
         EXPECT(w == w1 && same(back, Q));
         for (size_t i = 0; i < N; i++) EXPECT(okw[i] == 1);
+    }
+    {   // hash to curve from host pointers: the shards rebase the offset table of their run of messages
+        const size_t nm = 40000;
+        std::string data;
+        std::vector<uint64_t> off(nm + 1, 0);
+        for (size_t i = 0; i < nm; i++) { data.append(i % 71, (char)('a' + i % 26)); data += std::to_string(i); off[i + 1] = data.size(); }
+        const std::string dst = "Hash Bytes To Element In G1";
+        std::vector<G1Affine> H(nm), H1(nm);
+        std::vector<uint8_t> U(nm * 128), U1(nm * 128);
+        check(gpbc_hash_to_g1(data.data(), off.data(), nm, dst.data(), dst.size(), H.data()));
+        check(gpbc_hash_to_field(data.data(), off.data(), nm, dst.data(), dst.size(), 4, U.data()));
+        check(gpbc_set_host_sharding(0));
+        check(gpbc_hash_to_g1(data.data(), off.data(), nm, dst.data(), dst.size(), H1.data()));
+        check(gpbc_hash_to_field(data.data(), off.data(), nm, dst.data(), dst.size(), 4, U1.data()));
+        check(gpbc_set_host_sharding(1));
+        EXPECT(same(H, H1) && U == U1 && !H[0].IsInfinity() && !H[nm - 1].Equal(H[nm - 2]));
+        EXPECT(H[12345].Equal(HashToG1(data.substr(off[12345], off[12346] - off[12345]), dst)));
     }
     // point sums and the aggregate-verify sums: sum_i [c_i] P_i must equal the sum of the products, on any number of devices
     G1Affine A, A1, As; G2Affine B, B1, Bs;

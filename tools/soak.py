@@ -44,6 +44,11 @@ print("scalar multiplications ok  (%d each, %.1f s)" % (n, time.time() - t0), fl
 t0 = time.time()
 gt = bn254.pair_batch(P, Q)
 assert (gt == oracle_lib.pair_batch(P, Q, threads=threads)).all(), "pairing"
+if n > 16384:                                                 # the same pairings again in small calls: the pipelined one-launch Miller loop
+    want = gt.reshape(-1, 384)
+    for lo in range(0, n, 8192 + 37):
+        hi = min(n, lo + 8192 + 37)
+        assert (bn254.pair_batch(P.reshape(-1, 64)[lo:hi], Q.reshape(-1, 128)[lo:hi]).reshape(-1, 384) == want[lo:hi]).all(), "pipelined small batch"
 print("pairings ok  (%d, %.1f s)" % (n, time.time() - t0), flush=True)
 t0 = time.time()
 lens = rng.integers(0, 12, size=n // 4)

@@ -794,5 +794,67 @@ GPBC_NOINLINE Fe fe_inv(const Fe &x) {
     return fe_mul(y, fe_const(RC));
 }
 
+// Legendre symbol (x / p) by the same machinery: the "posdivsteps" of libsecp256k1's secp256k1_jacobi32_maybe_var (modinv32_impl.h,
+// Pieter Wuille, MIT) — divsteps that ADD instead of subtract, so f and g stay non-negative and the symbol can be tracked through
+// the quadratic-reciprocity rules (halving g flips it when f = 3, 5 mod 8; swapping flips it when f = g = 3 mod 4) — restated
+// here bit by bit with masks: batches of 30 steps with a 2 x 2 transition matrix applied to the full (f, g) per batch, until f = 1.
+// The number of steps a pair (p, x) needs has no proven bound of this size (measured on 20 000 random x: 690 .. 844); the function
+// answers 0 = "not determined" when f has not reached one within 40 batches (or x = 0), and the caller then takes the power
+// x^((p-1)/2).  ~25 k instructions against ~65 k for the power.  Any power of two is a square modulo p (p = 7 mod 8), so the
+// Montgomery factors of the representation do not change the symbol.
+GPBC_INLINE int32_t jac30_steps(int32_t eta, uint32_t f0, uint32_t g0, int32_t &tu, int32_t &tv, int32_t &tq, int32_t &tr, uint32_t &jac) {
+    uint32_t u = 1, v = 0, q = 0, r = 1, f = f0, g = g0;
+#pragma unroll 6
+    for (int i = 0; i < 30; i++) {
+        const uint32_t c1 = 0u - (g & 1u);                     // g odd
+        const uint32_t c2 = (uint32_t)(eta >> 31) & c1;         // ... and eta < 0: swap
+        jac ^= ((f & g) >> 1) & c2;
+        uint32_t t = (f ^ g) & c2; f ^= t; g ^= t;
+        t = (u ^ q) & c2; u ^= t; q ^= t;
+        t = (v ^ r) & c2; v ^= t; r ^= t;
+        eta = (int32_t)(((uint32_t)eta ^ c2) - c2);
+        g += f & c1; q += u & c1; r += v & c1;
+        g >>= 1; u <<= 1; v <<= 1; eta -= 1;
+        jac ^= (f >> 1) ^ (f >> 2);
+    }
+    tu = (int32_t)u; tv = (int32_t)v; tq = (int32_t)q; tr = (int32_t)r;
+    return eta;
+}
+GPBC_NOINLINE int fe_legendre(const Fe &x) {
+    Fe c = fe_canonical(fe_mul(x, fe_one()));
+    Inv30 g, f;
+    {
+        uint64_t acc = 0;
+        int have = 0, wi = 0;
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            acc |= (uint64_t)(uint32_t)c.v[i] << have;
+            have += LB;
+            if (have >= 30 && wi < 9) { g.v[wi++] = (int32_t)(acc & 0x3fffffffu); acc >>= 30; have -= 30; }
+        }
+        if (wi < 9) g.v[wi] = (int32_t)acc;
+    }
+    constexpr int32_t MOD[9] = INV30_P;
+#pragma unroll
+    for (int i = 0; i < 9; i++) f.v[i] = MOD[i];
+    int32_t eta = -1;
+    uint32_t jac = 0;
+    // (f, g) = (1, 1) is where every run with gcd 1 ends and stays; on the way there f can pass through 1 and leave it again, so a
+    // lane stops at the first batch boundary that finds f = 1 — the symbol is settled at that moment — and the wave runs until its
+    // last lane has stopped (27-29 batches for random x) or the budget of 40 is spent
+    auto f_is_one = [&]() {
+        int32_t rest = f.v[0] ^ 1;
+#pragma unroll
+        for (int i = 1; i < 9; i++) rest |= f.v[i];
+        return rest == 0;
+    };
+    for (int it = 0; it < 40 && !f_is_one(); it++) {
+        int32_t u, v, q, r;
+        eta = jac30_steps(eta, (uint32_t)f.v[0] | ((uint32_t)f.v[1] << 30), (uint32_t)g.v[0] | ((uint32_t)g.v[1] << 30), u, v, q, r, jac);
+        inv30_update_fg(f, g, u, v, q, r);
+    }
+    return f_is_one() ? 1 - 2 * (int)(jac & 1u) : 0;
+}
+
 }  // namespace gpbc
 #endif

@@ -27,8 +27,13 @@ template <class F> struct SvdwOf;
 template <> struct SvdwOf<Fe> { typedef SvdwFe type; };
 template <> struct SvdwOf<F2> { typedef SvdwF2 type; };
 
-// is_square: Legendre symbol by a^((p-1)/2) != -1 (0 counts as a square, as in RFC 9380); for Fp2 on the norm
+// is_square: Legendre symbol (fe_legendre; a^((p-1)/2) != -1 where that does not decide; 0 counts as a square, as in RFC 9380);
+// for Fp2 on the norm
 GPBC_INLINE bool g_is_square(const Fe &a) {
+#ifndef GPBC_IS_SQUARE_BY_POWER
+    const int j = fe_legendre(a);                                // divstep-based symbol; 0 = not determined (or a = 0)
+    if (j) return j > 0;
+#endif
     constexpr int32_t E12[NL] = F29_EXP_P12;
     Fe l = g_pow_limbs(a, E12);
     return !fe_is_zero(fe_norm(fe_add(l, fe_one())));

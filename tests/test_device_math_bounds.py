@@ -188,6 +188,28 @@ def test_safegcd_inversion_matches_fermat_and_oracle(hc):
     assert o1.tobytes() == exp and o2.tobytes() == exp
 
 
+def test_divstep_legendre_symbol(hc):
+    """fe_legendre (posdivsteps with the reciprocity rules, the is_square of hash to curve) against Euler's criterion: edge values,
+    powers of two, squares and non-squares; 0 (not determined) is allowed only for a = 0 or beyond the 960-step budget, and must
+    be rare."""
+    import random
+    random.seed(77)
+    vals = [0, 1, 2, 3, 4, 5, o.P - 1, o.P - 2, (o.P - 1) // 2, (o.P + 1) // 2, 1 << 253] + [1 << k for k in range(0, 254, 5)]
+    vals += [random.randrange(o.P) for _ in range(4000)] + [pow(random.randrange(1, o.P), 2, o.P) for _ in range(500)]
+    a = np.frombuffer(b"".join(o.fp_to_mont_bytes(v) for v in vals), dtype=np.uint8).copy()
+    out = np.zeros(len(vals), dtype=np.int8)
+    hc.hc_fp_legendre(vp(a), ctypes.c_size_t(len(vals)), vp(out))
+    undecided = 0
+    for v, j in zip(vals, out):
+        e = pow(v, (o.P - 1) // 2, o.P)
+        e = -1 if e == o.P - 1 else e
+        if j == 0:
+            undecided += v != 0
+        else:
+            assert int(j) == e, (v, int(j), e)
+    assert out[0] == 0 and undecided == 0
+
+
 def test_fixed_base_msm_under_bounds(hc):
     """The table-build and 32-additions-per-term loop of k_g1_fb_build / k_g1_fb_msm on the host under the bounds
     harness (a subset of table rows is built; scalars only use digits of that subset), against the oracle."""

@@ -179,6 +179,10 @@ void hc_fp_inv(const uint8_t *A, size_t n, uint8_t *out, uint8_t *out2) {
         fe_store(out2 + 32 * i, fe_inv_fermat(a));
     }
 }
+// (a / p) by the divstep-based symbol: 1, -1, or 0 where it does not decide within its 960 steps (and for a = 0)
+void hc_fp_legendre(const uint8_t *A, size_t n, int8_t *out) {
+    for (size_t i = 0; i < n; i++) out[i] = (int8_t)fe_legendre(fe_load(A + 32 * i));
+}
 void hc_gt_mul(const uint8_t *A, const uint8_t *B, size_t n, uint8_t *out) {
     for (size_t i = 0; i < n; i++) { F12 a, b; f12_load(a, A + 384 * i); f12_load(b, B + 384 * i); f12_store(out + 384 * i, f12_mul(a, b)); }
 }

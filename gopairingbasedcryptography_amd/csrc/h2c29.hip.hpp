@@ -29,15 +29,7 @@ template <> struct SvdwOf<F2> { typedef SvdwF2 type; };
 
 // is_square: Legendre symbol (fe_legendre; a^((p-1)/2) != -1 where that does not decide; 0 counts as a square, as in RFC 9380);
 // for Fp2 on the norm
-GPBC_INLINE bool g_is_square(const Fe &a) {
-#ifndef GPBC_IS_SQUARE_BY_POWER
-    const int j = fe_legendre(a);                                // divstep-based symbol; 0 = not determined (or a = 0)
-    if (j) return j > 0;
-#endif
-    constexpr int32_t E12[NL] = F29_EXP_P12;
-    Fe l = g_pow_limbs(a, E12);
-    return !fe_is_zero(fe_norm(fe_add(l, fe_one())));
-}
+GPBC_INLINE bool g_is_square(const Fe &a) { return fe_is_square(a); }
 GPBC_INLINE bool g_is_square(const F2 &a) { return g_is_square(fe_norm(fe_add(fe_sqr(a.a0), fe_sqr(a.a1)))); }
 GPBC_INLINE Fe g_sqrt(const Fe &a, bool &ok) { return fe_sqrt(a, ok); }
 GPBC_INLINE F2 g_sqrt(const F2 &a, bool &ok) { return f2_sqrt(a, ok); }

@@ -114,6 +114,43 @@ GPBC_INLINE Fe fe_sqrt(const Fe &a, bool &ok) {
     ok = g_equal(fe_sqr(y), a);
     return y;
 }
+// is_square in Fp: the divstep-based Legendre symbol (fe29.hip.hpp), the power a^((p-1)/2) where that does not decide; 0 counts as
+// a square (RFC 9380)
+GPBC_INLINE bool fe_is_square(const Fe &a) {
+#ifndef GPBC_IS_SQUARE_BY_POWER
+    const int j = fe_legendre(a);
+    if (j) return j > 0;
+#endif
+    constexpr int32_t E12[NL] = F29_EXP_P12;
+    Fe l = g_pow_limbs(a, E12);
+    return !fe_is_zero(fe_norm(fe_add(l, fe_one())));
+}
+// Fp2 by the norm: for a = a0 + a1 i with a1 != 0, s = sqrt(a0^2 + a1^2) exists exactly when a is a square; exactly one of
+// (a0 + s) / 2 and (a0 - s) / 2 is a square in Fp (their product is -a1^2 / 4), the Legendre symbol says which, x0 is its root
+// and x1 = a1 / (2 x0).  Two Fp powers, one symbol and one safegcd inversion (~170 k instructions) in place of the two Fp2 powers
+// of the complex method below (~340 k).  Either root serves: every caller fixes the sign afterwards (sgn0 / the wire flag).
+// -DGPBC_F2_SQRT_COMPLEX selects the previous form (A/B runs).
+#ifndef GPBC_F2_SQRT_COMPLEX
+GPBC_INLINE F2 f2_sqrt(const F2 &a, bool &ok) {
+    F2 x;
+    if (fe_is_zero(fe_norm(a.a1))) {                             // a in Fp: sqrt(a0), or i sqrt(-a0) (-1 is not a square)
+        bool ok0;
+        const bool sq = fe_is_square(a.a0);
+        Fe r = fe_sqrt(sq ? a.a0 : fe_neg(a.a0), ok0);
+        x = sq ? F2{r, fe_zero()} : F2{fe_zero(), r};
+    } else {
+        bool ok0;
+        const Fe n = fe_norm(fe_add(fe_sqr(a.a0), fe_sqr(a.a1)));
+        const Fe s = fe_sqrt(n, ok0);
+        Fe d = fe_halve(fe_norm(fe_add(a.a0, s)));
+        if (!fe_is_square(d)) d = fe_norm(fe_sub(d, s));
+        const Fe x0 = fe_sqrt(d, ok0);
+        x = F2{x0, fe_mul(a.a1, fe_inv(fe_norm(fe_dbl(x0))))};
+    }
+    ok = g_equal(f2_sqr(x), a);
+    return x;
+}
+#else
 // Fp2, complex method (Adj, Rodriguez-Henriquez, "Square root computation over even extension fields", Alg. 9):
 // a1 = a^((p-3)/4), x0 = a1 a, alpha = a1 x0; alpha = -1 -> i x0, else (1 + alpha)^((p-1)/2) x0
 GPBC_INLINE F2 f2_sqrt(const F2 &a, bool &ok) {
@@ -128,6 +165,7 @@ GPBC_INLINE F2 f2_sqrt(const F2 &a, bool &ok) {
     ok = g_equal(f2_sqr(x), a);
     return x;
 }
+#endif
 
 // ---- coordinates <-> bytes
 GPBC_INLINE bool fe_wire_load(Fe &r, const uint8_t *p, uint8_t first_mask, bool &zero) {

@@ -127,6 +127,12 @@ def test_wrapper_rejects_malformed_device_arguments():
         lambda: bn254.g1_scalar_mul_sum(z(3 * 64), z(4 * 32)),
         lambda: bn254.multi_pair_fixed_q(z(6 * 64), z(4 * 128)),              # 6 points are not a multiple of the 4-point list
         lambda: bn254.g1_unmarshal(z(65), elem_bytes=32),
+        lambda: bn254.hash_to_field([b"abc"], b"dst", 3),                      # count must be 2 or 4
+        lambda: bn254.hash_to_g1(z(10), b"dst"),                              # device-style messages without an offset table
+        lambda: bn254.hash_to_g2(z(10), b"dst", msg_off=torch.tensor([0, 10], dtype=torch.int32)),   # table must be int64
+        lambda: bn254.hash_to_g1(z(10), b"dst", msg_off=torch.tensor([0, 10], dtype=torch.int64)),   # right shapes, but host tensors
+        lambda: bn254.hash_to_field(np.frombuffer(b"abc", dtype=np.uint8), b"dst", 2, msg_off=np.array([0, 5], dtype=np.uint64)),   # offsets beyond the buffer
+        lambda: bn254.g1_scalar_mul(np.zeros(64, dtype=np.uint8), np.zeros(4 * 32, dtype=np.uint8), out=np.zeros(3 * 64, dtype=np.uint8)),   # host out too small
     ]
     bn254._slots = bn254._slots or {0: 0}                                     # as after init(0); no device is touched below
     for i, call in enumerate(bad):

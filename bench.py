@@ -46,6 +46,7 @@ FP_MUL_MILLER, FP_MUL_FINAL_EXP, FP_MUL_G1, FP_MUL_G2 = 7000, 5000, 2500, 7500  
 # nominal split of the Miller loop between its two kernels, from SURVEY §8a-1's per-step figures (point doubling + line ~28
 # of ~99 Fp-mul per doubling step): 2000 for the line phase, 5000 for the Fp12 accumulator
 NOMINAL_FP_MUL = {"k_miller_lines": 2000, "k_miller_accumulate": 5000, "k_final_exp": FP_MUL_FINAL_EXP}
+EXECUTED_MAD = {}                         # filled from profiles/executed_mads.json (tests/test_device_math_bounds.py writes it: exact counts of the device code)
 PEAK_TMAC_PER_S = 34.9                    # measured: v_mad_u64_u32, 8 waves/SIMD (profiles/r01_microbench_valu.txt)
 HBM_PEAK_GBS = 8000.0
 
@@ -110,6 +111,9 @@ def cpu_baseline(P, Q, gt_gpu, B):
 
 
 def main():
+    em = os.path.join(ROOT, "profiles", "executed_mads.json")
+    if os.path.exists(em):
+        EXECUTED_MAD.update(json.load(open(em)).get("mads_per_unit", {}))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -232,6 +236,11 @@ def main():
         nm = names.raw[32 * i:32 * i + 32].split(b"\0")[0].decode()
         kern[nm] = {"ms_per_step": ms[i] / args.steps, "launches_per_step": cnt[i] / args.steps, "ms_per_launch": ms[i] / cnt[i]}
     dt = max_over_ranks(dt)
+    # the roofline's denominator and the shader clock, measured in this process right after the timed steps (rank 0's device)
+    probe = (ctypes.c_double * 4)()
+    _lib.check(lib.gpbc_valu_probe(probe))
+    peak_now, clock_hz = probe[0] / 1e12, probe[1]
+    n_simd = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
     miller_ms = sum(kern[k]["ms_per_step"] for k in ("k_miller_lines", "k_miller_accumulate") if k in kern)
     fexp_ms = kern.get("k_final_exp", {}).get("ms_per_step", float("nan"))
 
@@ -261,10 +270,21 @@ def main():
         result["config"]["rehearsal"] = "NOT A MEASUREMENT: %d ranks share one GPU (GPBC_BENCH_REHEARSAL=1), gloo, no library communicator" % world
     # ---- roofline, VALU integer-MAC bound: the single kernel with the largest time per step
     frac = lambda fpmul, t_ms: fpmul * MAC_PER_FP_MUL * B / (t_ms * 1e-3) / 1e12 / PEAK_TMAC_PER_S
+    # VALU instructions per wave of the same kernels from the last committed PMC pass (tools/pmc_run.sh -> profiles/pmc_counters.json):
+    # NOT measured by this run — rocprofv3 counters need their own passes — but independent of the box's clock
+    pmc = {}
+    pp = os.path.join(ROOT, "profiles", "pmc_counters.json")
+    if os.path.exists(pp):
+        pmc = json.load(open(pp))
     for k, v in kern.items():
         if k in NOMINAL_FP_MUL:
             v["nominal_fp_mul"] = NOMINAL_FP_MUL[k]
             v["frac"] = frac(NOMINAL_FP_MUL[k], v["ms_per_step"])
+            v["frac_same_run_peak"] = v["frac"] * PEAK_TMAC_PER_S / peak_now
+            # clock-normalised: SIMD cycles the chip spent per pairing in this kernel (wall time x measured shader clock x SIMDs / batch)
+            v["simd_cycles_per_pairing"] = v["ms_per_step"] * 1e-3 * clock_hz * n_simd / B
+            if k in pmc.get("kernels", {}):
+                v["valu_instr_per_wave_from_profiles"] = pmc["kernels"][k].get("valu_instr_per_wave")
     dom = max((k for k in kern if k in NOMINAL_FP_MUL), key=lambda k: kern[k]["ms_per_step"])
     launches = kern[dom]["launches_per_step"]
     achieved = NOMINAL_FP_MUL[dom] * MAC_PER_FP_MUL * (B / launches) / (kern[dom]["ms_per_launch"] * 1e-3) / 1e12
@@ -280,16 +300,26 @@ def main():
                 per_kernel_traffic[k] = per_launch * (B / t["batch"])
         if len(per_kernel_traffic) == len(NOMINAL_FP_MUL):
             traffic = sum(per_kernel_traffic.values())
+    def executed(unit, t_ms):
+        """MADs the device code actually issues (profiles/executed_mads.json, counted by the interval harness) against the same-run peak:
+        the share of the VALU's MAD rate spent on limb products, where `frac` prices SURVEY's nominal 136 MACs per Fp-mul"""
+        m = EXECUTED_MAD.get(unit)
+        return {"executed_mad_per_pairing": m, "executed_mad_frac_of_same_run_peak": m * B / (t_ms * 1e-3) / 1e12 / peak_now} if m else {}
     result["roofline"] = {
         "bound": "valu", "kernel": dom, "achieved": achieved, "peak": PEAK_TMAC_PER_S, "unit": "TMAC/s",
         "frac": achieved / PEAK_TMAC_PER_S,
+        "peak_same_run": peak_now, "frac_same_run": achieved / peak_now,
+        "probe": {"what": "gpbc_valu_probe: dependency-free v_mad_u64_u32 at 8 waves/SIMD, run in this process after the timed steps",
+                  "tmac_per_s": peak_now, "shader_clock_GHz": clock_hz / 1e9, "simd_cycles_per_wave_instr": probe[2], "ms": probe[3]},
+        "pmc_source": (pmc.get("source", "profiles/pmc_counters.json") + " — counters are from that committed rocprofv3 run, NOT from this run") if pmc else None,
         "kernel_ms_per_launch": kern[dom]["ms_per_launch"], "kernel_launches_per_step": launches, "pairs_per_launch": B / launches,
-        "traffic": traffic, "traffic_unit": "HBM bytes per step, all kernels (PMC FETCH_SIZE x2 + WRITE_SIZE)",
+        "traffic": traffic, "traffic_unit": "HBM bytes per step, all kernels (PMC FETCH_SIZE x2 + WRITE_SIZE); from profiles/pmc_traffic.json (a committed rocprofv3 --pmc run), NOT measured by this run",
         "traffic_per_kernel": per_kernel_traffic or None, "algorithmic_bytes": algo_bytes,
         "traffic_over_algorithmic": (traffic / algo_bytes) if traffic else None,
         "kernels": kern,
-        "stages": {"miller_loop (k_miller_lines + k_miller_accumulate)": {"ms": miller_ms, "nominal_fp_mul": FP_MUL_MILLER, "frac": frac(FP_MUL_MILLER, miller_ms)},
-                   "k_final_exp": {"ms": fexp_ms, "nominal_fp_mul": FP_MUL_FINAL_EXP, "frac": frac(FP_MUL_FINAL_EXP, fexp_ms)}},
+        "stages": {"miller_loop (k_miller_lines + k_miller_accumulate)": {"ms": miller_ms, "nominal_fp_mul": FP_MUL_MILLER, "frac": frac(FP_MUL_MILLER, miller_ms),
+                                                                           **executed("miller_loop", miller_ms)},
+                   "k_final_exp": {"ms": fexp_ms, "nominal_fp_mul": FP_MUL_FINAL_EXP, "frac": frac(FP_MUL_FINAL_EXP, fexp_ms), **executed("final_exp", fexp_ms)}},
         "whole_pairing_frac": frac(FP_MUL_MILLER + FP_MUL_FINAL_EXP, miller_ms + fexp_ms),
         "hbm_GBs_algorithmic": algo_bytes / ((miller_ms + fexp_ms) * 1e-3) / 1e9, "hbm_peak_GBs": HBM_PEAK_GBS,
         "note": "integer carry-chain work: bound is VALU v_mad_i64_i32 issue, not HBM/MFMA (SURVEY.md §8d); peak = measured "
@@ -311,6 +341,12 @@ def main():
             d = max_over_ranks((time.perf_counter() - t1) / 2)
             sec[name + "_scalar_mults_per_s"] = world * B / d
             sec[name + "_frac_of_valu_peak"] = nominal * MAC_PER_FP_MUL * B / d / 1e12 / PEAK_TMAC_PER_S
+            # the nominal count above is SURVEY's (2 500 / 7 500 Fp-mul x 136); what the kernel EXECUTES is counted by the interval
+            # harness (tools/bounds_check.cpp runs the device code on the host and counts its limb products): MADs per unit
+            ex = EXECUTED_MAD.get(name)
+            if ex:
+                sec[name + "_executed_mad_per_unit"] = ex
+                sec[name + "_executed_mad_frac_of_same_run_peak"] = ex * B / d / 1e12 / peak_now
 
         # The remaining lines (wire formats, hash to curve, fixed-base tables, GT.Exp) are per-GPU rates of independent
         # kernels: measured on the single-GPU run only, and never allowed to take the headline JSON line down with them.

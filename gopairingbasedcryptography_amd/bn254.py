@@ -704,9 +704,8 @@ def _hash_messages(what, msgs, dst, msg_off=None):
     _ensure_init()
     lib = _lib.load()
     dst = bytes(dst)
-    if len(dst) > 255:                                           # RFC 9380 section 5.3.3
-        import hashlib
-        dst = hashlib.sha256(b"H2C-OVERSIZE-DST-" + dst).digest()
+    if len(dst) > 255:                                           # gnark's ExpandMsgXmd refuses it ("invalid domain size"), so does the Go shim
+        raise ValueError("invalid domain size (>255 bytes)")
     width = G1_BYTES if what == 0 else G2_BYTES if what == 1 else 32 * what
     dbuf = ctypes.create_string_buffer(dst, len(dst) if dst else 1)
     count = (ctypes.c_int(what),) if what >= 2 else ()

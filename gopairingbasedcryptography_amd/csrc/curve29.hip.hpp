@@ -303,22 +303,12 @@ template <class F> GPBC_INLINE void scalar_mul29_jac(JacP<F> &acc, const AffP<F>
     for (int i = top >> 1; i >= 0; i--) {
         const int b = 2 * i;
         const int idx = 4 * (int)((s.k1[b >> 5] >> (b & 31)) & 3) + (int)((s.k2[b >> 5] >> (b & 31)) & 3);
-#ifndef GPBC_TABLE_LOAD_AT_USE
         AffP<F> t;
         tab_load(tab, idx, t);                           // requested before the doublings: its HBM latency passes behind them
                                                          // (entry 0 is never used; its row exists)
         jac_dbl(acc, acc);
         jac_dbl(acc, acc);
         if (idx) jac_add_mixed(acc, acc, t);
-#else
-        jac_dbl(acc, acc);
-        jac_dbl(acc, acc);
-        if (idx) {
-            AffP<F> t;
-            tab_load(tab, idx, t);
-            jac_add_mixed(acc, acc, t);
-        }
-#endif
     }
     if (!acc.inf) acc.z = g_mul(acc.z, W);               // back from the curve scaled by W
 }
@@ -424,19 +414,10 @@ GPBC_INLINE void scalar_mul29_gls(JacP<F2> &acc, const AffP<F2> &base, const uin
     for (int i = top; i >= 0; i--) {
         const int w = i >> 5, b = i & 31;
         const int idx = (int)((s.k[0][w] >> b) & 1) | (int)(((s.k[1][w] >> b) & 1) << 1) | (int)(((s.k[2][w] >> b) & 1) << 2) | (int)(((s.k[3][w] >> b) & 1) << 3);
-#ifndef GPBC_TABLE_LOAD_AT_USE
         AffP<F2> t;
         tab_load(tab, idx, t);                           // before the doubling, as in the GLV loop
         jac_dbl(acc, acc);
         if (idx) jac_add_mixed(acc, acc, t);
-#else
-        jac_dbl(acc, acc);
-        if (idx) {
-            AffP<F2> t;
-            tab_load(tab, idx, t);
-            jac_add_mixed(acc, acc, t);
-        }
-#endif
     }
     if (!acc.inf) acc.z = f2_mul(acc.z, W);
 }

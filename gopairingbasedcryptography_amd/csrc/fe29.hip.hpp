@@ -52,13 +52,13 @@ struct Fe {
 };
 
 #ifdef GPBC_BOUNDS
-struct BoundStats { double max_col = 0, max_limb = 0, max_vb = 0; long muls = 0, norms = 0, muls2 = 0, reduces = 0; };
+struct BoundStats { double max_col = 0, max_limb = 0, max_vb = 0; long muls = 0, norms = 0, muls2 = 0, reduces = 0, mads = 0; };   // mads: the v_mad_i64_i32 the DEVICE form of the same calls executes
 inline BoundStats &bound_stats() { static thread_local BoundStats s; return s; }   // per thread (the pair harness runs two)
 inline void bound_stats_merge(BoundStats &into, BoundStats &from) {
     if (from.max_col > into.max_col) into.max_col = from.max_col;
     if (from.max_limb > into.max_limb) into.max_limb = from.max_limb;
     if (from.max_vb > into.max_vb) into.max_vb = from.max_vb;
-    into.muls += from.muls; into.norms += from.norms; into.muls2 += from.muls2; into.reduces += from.reduces;
+    into.muls += from.muls; into.norms += from.norms; into.muls2 += from.muls2; into.reduces += from.reduces; into.mads += from.mads;
     from = BoundStats();
 }
 inline void bounds_fail(const char *what, double got, double lim) {
@@ -186,6 +186,7 @@ GPBC_INLINE Fe fe_mul_core(const Fe &a, const Fe &b, const Fe &c, const Fe &d) {
         }
         bound_stats().muls++;
         if (TWO) bound_stats().muls2++;
+        bound_stats().mads += (TWO ? 2 : 1) * NL * NL + NL * NL;      // limb products + reduction terms
     }
 #endif
     // Column-wise (product-scanning) Montgomery: one running 64-bit accumulator; column k collects its limb
@@ -323,6 +324,7 @@ GPBC_INLINE void fe_sqrdiff_mul_dual(Fe &r0, Fe &r1, const Fe &a0, const Fe &a1)
 #ifdef GPBC_BOUNDS
     r0 = fe_mul_core<true>(a0, a0, fe_neg(a1), a1);
     r1 = fe_mul_core<false>(fe_dbl(a0), a1, a0, a1);
+    bound_stats().mads -= 2 * NL * NL - 2 * (NL * (NL + 1) / 2);       // the device form takes the symmetric halves of the two squares: 45 + 45, not 81 + 81
 #else
     int32_t d0[NL], n1[NL], dn1[NL], m0[NL], m1[NL];
 #pragma unroll
@@ -372,7 +374,7 @@ GPBC_INLINE void fe_sqrdiff_mul_dual(Fe &r0, Fe &r1, const Fe &a0, const Fe &a1)
 #define GPBC_PASS9(x) x.v[0], x.v[1], x.v[2], x.v[3], x.v[4], x.v[5], x.v[6], x.v[7], x.v[8]
 #define GPBC_PACK9(x) Fe{{x##0, x##1, x##2, x##3, x##4, x##5, x##6, x##7, x##8}}
 
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(GPBC_BOUNDS) && !defined(GPBC_INLINE_LEAVES)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GPBC_BOUNDS)
 // Leaf functions with every limb passed as a scalar argument: scalars go in VGPRs v0..v31 (aggregates larger than
 // 16 dwords would travel through scratch), so the tower above can stay inlined while the ~200 / ~290-instruction
 // multipliers exist once in the code object (I-cache).
@@ -404,6 +406,7 @@ GPBC_INLINE Fe fe_sqr_core(const Fe &a) {
         }
         for (int i = 0; i < NL; i++) if (2 * limb_mag(a, i) >= 2147483648.0) bounds_fail("fe_sqr doubled limb", 2 * limb_mag(a, i), 2147483648.0);
         bound_stats().muls++;
+        bound_stats().mads += NL * (NL + 1) / 2 + NL * NL;
     }
 #endif
     int32_t d[NL], m[NL];
@@ -441,7 +444,7 @@ GPBC_INLINE Fe fe_sqr_core(const Fe &a) {
 #endif
     return r;
 }
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(GPBC_BOUNDS) && !defined(GPBC_INLINE_LEAVES)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GPBC_BOUNDS)
 __device__ __noinline__ Fe fe_sqr_leaf(GPBC_ARGS9(a)) { Fe a = GPBC_PACK9(a); return fe_sqr_core(a); }
 GPBC_INLINE Fe fe_sqr(const Fe &a) { return fe_sqr_leaf(GPBC_PASS9(a)); }
 #else
@@ -529,6 +532,7 @@ GPBC_INLINE Fe fe_reduce_arith(const Fe &a) {
 #endif
     constexpr int32_t P8 = f29_p(NL - 1);
     int32_t k = (int32_t)rintf((float)a.v[NL - 1] * (1.0f / (float)P8));
+    GPBC_B(bound_stats().mads += NL;)
     Fe r;
     int32_t hi_prev = 0;
 #pragma unroll
@@ -769,6 +773,7 @@ GPBC_NOINLINE Fe fe_inv(const Fe &x) {
 #pragma unroll
     for (int i = 0; i < 9; i++) { f.v[i] = MOD[i]; d.v[i] = 0; e.v[i] = i == 0 ? 1 : 0; }
     int32_t zeta = -1;
+    GPBC_B(bound_stats().mads += 20 * (6 * 9 + 4 * 9);)          // the 64-bit limb products of the 20 matrix applications
     for (int it = 0; it < 20; it++) {
         int32_t u, v, q, r;
         zeta = inv30_divsteps(zeta, (uint32_t)f.v[0], (uint32_t)g.v[0], u, v, q, r);

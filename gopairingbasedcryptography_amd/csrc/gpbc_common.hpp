@@ -24,16 +24,12 @@ using namespace gpbc;
 // converts to the internal 9 x 29-bit signed-limb form on load and back to canonical bytes on store.
 constexpr int BLOCK = 64;
 static_assert(BLOCK == 64, "one wave per workgroup: the LDS slots of the F2 leaf (tower29.hip.hpp) are indexed by the lane number");
-#ifndef GPBC_WAVES_PER_SIMD
 #define GPBC_WAVES_PER_SIMD 2
-#endif
 #define GPBC_KERNEL __global__ void __launch_bounds__(BLOCK, GPBC_WAVES_PER_SIMD)
 // G1 arithmetic is light enough on registers for three waves per SIMD (168 VGPRs): measured +12 % over two, while the Fp2 /
 // Fp12 kernels lose 15-75 % to the extra spills (profiles/r01_microbench_valu2.txt explains the gain: a wave issues
 // at most one VALU instruction per ~4.5 cycles, so the 2.4-cycle VOP2 glue only gets cheaper with more waves).
-#ifndef GPBC_WAVES_G1
 #define GPBC_WAVES_G1 3
-#endif
 #define GPBC_KERNEL_G1 __global__ void __launch_bounds__(BLOCK, GPBC_WAVES_G1)
 
 __device__ __forceinline__ bool g1_bytes_inf(const uint8_t *p) { return bytes_all_zero(p, 16); }
@@ -122,6 +118,8 @@ template <class Up, class Run, class Down> int pipelined_chunks(size_t n, size_t
 // Bucket (Pippenger) multi-scalar multiplication over variable bases (gpbc_msm.hip): sum_i [s_i] P_i, n terms in device memory,
 // one affine point out; asynchronous on `st`.  Used by the scalar_mul_sum entries from MSM_MIN_TERMS terms on.
 constexpr size_t MSM_MIN_TERMS = 16384;
+constexpr int MSM_SKEWED = 1;                     // msm_dev: the scalars are too unevenly spread for buckets (not an error; nothing was written)
+constexpr uint32_t MSM_MAX_BUCKET_BASE = 256;     // longest bucket accepted: this + 8 x the mean bucket length
 int msm_dev(bool g2, const void *d_bases, const void *d_scalars, size_t n, void *d_out, hipStream_t st);
 // RCCL communicator of the current device (gpbc_core.hip): number of ranks (0 = none), this device's rank, all-gather
 int comm_ranks();
@@ -195,6 +193,11 @@ struct Scratch {
         return p;
     }
 };
+// Library-owned PINNED host memory, one grow-only buffer per (device, stream): small host tables (segment / chunk offsets) are
+// copied here first and travel to the device by a stream-ordered DMA from memory that only this library writes, and the kernels'
+// echo of what they consumed comes back the same way.  The caller must hold the scratch lock of the stream from the moment it
+// writes the buffer until it has synchronised the stream (multi_pair_core does).
+int pinned_staging(hipStream_t stream, size_t bytes, uint8_t **out);
 static inline int lines_workspace(hipStream_t stream, size_t pairs, int32_t **out) { return stream_workspace(stream, pairs * LINE_BYTES_PER_PAIR, out); }
 void free_workspaces();
 

@@ -120,7 +120,10 @@ int run_sharded(size_t n, size_t min_units, const std::function<int(size_t, size
 }
 
 // ---- internal workspace, one grow-only buffer per (bound device slot, stream)
-struct StreamWs { int device; hipStream_t stream; int kind; void *ptr; size_t bytes; };      // device = index into g_ctx; kind 0 = workspace, 1 + level = scratch
+struct StreamWs { int device; hipStream_t stream; int kind; void *ptr; size_t bytes; };      // device = index into g_ctx; kind 0 = workspace, 1 + level = scratch, KIND_PINNED = pinned host staging
+constexpr int KIND_PINNED = 100;
+static hipError_t ws_alloc(int kind, void **p, size_t bytes) { return kind == KIND_PINNED ? hipHostMalloc(p, bytes, hipHostMallocDefault) : hipMalloc(p, bytes); }
+static hipError_t ws_free(int kind, void *p) { return kind == KIND_PINNED ? hipHostFree(p) : hipFree(p); }
 static std::mutex g_ws_mu;
 static std::vector<StreamWs> g_ws;
 static int stream_buffer(int kind, hipStream_t stream, size_t bytes, void **out) {
@@ -130,25 +133,26 @@ static int stream_buffer(int kind, hipStream_t stream, size_t bytes, void **out)
         if (w.device == dev && w.stream == stream && w.kind == kind) {
             if (w.bytes < bytes) {
                 HIP_TRY(hipStreamSynchronize(stream));
-                HIP_TRY(hipFree(w.ptr));
+                HIP_TRY(ws_free(kind, w.ptr));
                 w.ptr = nullptr; w.bytes = 0;
-                HIP_TRY(hipMalloc(&w.ptr, bytes));
+                HIP_TRY(ws_alloc(kind, &w.ptr, bytes));
                 w.bytes = bytes;
             }
             *out = w.ptr;
             return GPBC_OK;
         }
     void *ptr = nullptr;
-    HIP_TRY(hipMalloc(&ptr, bytes));
+    HIP_TRY(ws_alloc(kind, &ptr, bytes));
     g_ws.push_back(StreamWs{dev, stream, kind, ptr, bytes});
     *out = ptr;
     return GPBC_OK;
 }
 int stream_workspace(hipStream_t stream, size_t bytes, int32_t **out) { return stream_buffer(0, stream, bytes, (void **)out); }
 int stream_scratch(hipStream_t stream, int level, size_t bytes, void **out) { return stream_buffer(1 + level, stream, bytes, out); }
+int pinned_staging(hipStream_t stream, size_t bytes, uint8_t **out) { return stream_buffer(KIND_PINNED, stream, bytes < 4096 ? 4096 : bytes, (void **)out); }
 void free_workspaces() {
     std::lock_guard<std::mutex> lk(g_ws_mu);
-    for (auto &w : g_ws) if (w.ptr) { if (g_ctx[w.device].hip >= 0) (void)hipSetDevice(g_ctx[w.device].hip); (void)hipFree(w.ptr); }
+    for (auto &w : g_ws) if (w.ptr) { if (g_ctx[w.device].hip >= 0) (void)hipSetDevice(g_ctx[w.device].hip); (void)ws_free(w.kind, w.ptr); }
     g_ws.clear();
 }
 
@@ -418,6 +422,59 @@ int gpbc_profile_end(char *names_out, double *total_ms_out, int *launches_out, i
     g_prof.clear();
     *n_kernels_out = n;
     return rc;
+}
+
+// the dependency-free MAD rate and the shader clock, same process, same moment (tools/microbench_valu.hip is the long form)
+__global__ void __launch_bounds__(256) k_valu_probe(uint64_t *out, int iters, uint32_t a, uint32_t b) {
+    uint64_t acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) acc[c] = threadIdx.x + c;
+    const uint64_t t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[c]) : "v"(a), "v"(b) : "vcc");
+    }
+    const uint64_t t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    uint64_t r = acc[0] + acc[1] + acc[2] + acc[3];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out[0] = t1 - t0; out[1] = r1 - r0; }
+    if (r == 0x123456789abcdefULL) out[2] = r;                  // keeps the chains alive
+}
+int gpbc_valu_probe(double *out4) {
+    if (!out4) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    TRY(bind_device());
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, current_device()));
+    const int ncu = prop.multiProcessorCount, waves_per_simd = 8, iters = 4096;
+    DevBuf d;
+    TRY(d.alloc(3 * sizeof(uint64_t)));
+    HIP_TRY(hipMemset(d.p, 0, 3 * sizeof(uint64_t)));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    k_valu_probe<<<ncu * waves_per_simd, 256>>>((uint64_t *)d.p, 16, 3u, 5u);        // warm-up (clocks, code object)
+    float best = 1e30f;
+    uint64_t h[3] = {0, 0, 0}, hb[3] = {0, 0, 0};
+    int rc = check_launch("k_valu_probe");
+    for (int rep = 0; rep < 3 && rc == GPBC_OK; rep++) {
+        float ms = 0;
+        if (hipEventRecord(e0, nullptr) != hipSuccess) rc = fail(GPBC_ERR_HIP, "hipEventRecord failed");
+        k_valu_probe<<<ncu * waves_per_simd, 256>>>((uint64_t *)d.p, iters, 3u, 5u);
+        if (rc == GPBC_OK) rc = check_launch("k_valu_probe");
+        if (rc == GPBC_OK && (hipEventRecord(e1, nullptr) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess)) rc = fail(GPBC_ERR_HIP, "timing of the probe failed");
+        if (rc == GPBC_OK) rc = d.download(h, sizeof h);
+        if (rc == GPBC_OK && ms < best) { best = ms; memcpy(hb, h, sizeof h); }
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    TRY(rc);
+    const double lane_ops = (double)ncu * waves_per_simd * 256.0 * iters * 8 * 4;
+    const double clock_hz = hb[1] ? (double)hb[0] / ((double)hb[1] / 100e6) : 0.0;
+    const double wave_instr_per_simd = (double)waves_per_simd * iters * 8 * 4;      // each SIMD runs waves_per_simd waves of the 4 per block
+    out4[0] = lane_ops / (best * 1e-3);
+    out4[1] = clock_hz;
+    out4[2] = clock_hz ? (best * 1e-3 * clock_hz) / wave_instr_per_simd : 0.0;
+    out4[3] = best;
+    return GPBC_OK;
 }
 
 int gpbc_fp_mul_batch(const void *a, const void *b, size_t n, void *out) {

@@ -5,10 +5,7 @@
 // Scalar multiplication: a lane owns SMUL_K points (t, t+T, t+2T, ...; T = ceil(n / SMUL_K)) whose Jacobian results share
 // one field inversion.  Measured on MI355X (2^20 points): K = 1 -> 36.9 M G1 / 15.0 M G2 per second, K = 2 -> 36.9 / 13.7,
 // K = 4 -> 35.9 / 13.3: holding K results costs more in registers and scratch than the shared inversion saves, so K = 1.
-#ifndef GPBC_SMUL_K
-#define GPBC_SMUL_K 1
-#endif
-constexpr int SMUL_K = GPBC_SMUL_K;
+constexpr int SMUL_K = 1;
 GPBC_KERNEL_G1 k_g1_scalar_mul(const uint8_t *__restrict__ bases, int shared_base, const uint8_t *__restrict__ scalars, uint8_t *__restrict__ out, size_t n, int32_t *__restrict__ tabws) {
     size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     size_t T = (n + SMUL_K - 1) / SMUL_K;
@@ -288,58 +285,28 @@ static int sum_one(bool g2, const void *pts, size_t n, void *out) {
     TRY(sync_default());
     return dO.download(out, pt);
 }
-// Partial sums of the shards of a host-pointer call, combined on the first device: one point per shard, exchanged by RCCL
-// (ONE all-gather of a point per rank, in-process group call) when gpbc_comm_init_all() made a communicator for every bound
-// device, through the host otherwise.  `partial(lo, hi, d_out)` leaves the shard's sum in device memory at d_out (stream 0).
+// Partial sums of the shards of a host-pointer call: every shard leaves one point in the host array `parts` and the calling
+// thread's device adds them up.  No collective here — the data of a host-pointer call is on the host anyway; RCCL carries the
+// partial sums only where they are device-resident per rank (gpbc_g1/g2_scalar_mul_sum_dev).
+// `partial(lo, hi, d_out)` leaves the shard's sum in device memory at d_out (stream 0).
 static int sharded_point_sum(bool g2, size_t n, size_t min_units, const std::function<int(size_t, size_t, uint8_t *)> &partial, void *out) {
     const size_t pt = g2 ? GPBC_G2_BYTES : GPBC_G1_BYTES;
     const int nd = device_count_initialised();
-    std::vector<uint8_t> parts((size_t)(nd > 0 ? nd : 1) * pt, 0);
-    std::vector<uint8_t *> d_part((size_t)(nd > 0 ? nd : 1), nullptr), d_all((size_t)(nd > 0 ? nd : 1), nullptr);
+    std::vector<uint8_t> parts((size_t)(nd > 0 ? nd : 1) * pt, 0);   // rows of devices without a shard stay the point at infinity
     std::atomic<int> used{0};
-    const bool rccl = comm_ranks() == nd && nd > 1;
-    int rc = run_sharded(n, min_units, [&](size_t lo, size_t hi) {
+    const int before = gpbc_get_device();
+    TRY(run_sharded(n, min_units, [&](size_t lo, size_t hi) {
         TRY(bind_device());
         const int idx = gpbc_get_device();
         used.fetch_add(1);
-        uint8_t *dp = nullptr;
-        HIP_TRY(hipMalloc((void **)&dp, pt));
-        d_part[idx] = dp;
-        TRY(partial(lo, hi, dp));
+        DevBuf dp;
+        TRY(dp.alloc(pt));
+        TRY(partial(lo, hi, dp.u8()));
         TRY(sync_default());
-        HIP_TRY(hipMemcpy(parts.data() + (size_t)idx * pt, dp, pt, hipMemcpyDeviceToHost));   // used when no communicator spans the shards
-        return (int)GPBC_OK;
-    });
-    auto release = [&]() {
-        for (int i = 0; i < nd; i++) {
-            if (d_part[i] || d_all[i]) { (void)gpbc_set_device(i); (void)bind_device(); }
-            if (d_part[i]) (void)hipFree(d_part[i]);
-            if (d_all[i]) (void)hipFree(d_all[i]);
-        }
-        (void)gpbc_set_device(0);
-    };
-    const int before = gpbc_get_device();
-    if (rc == GPBC_OK && used.load() > 1 && rccl) {
-        // every rank contributes its point (ranks whose shard was empty contribute the point at infinity = zeros)
-        for (int i = 0; i < nd && rc == GPBC_OK; i++) {
-            (void)gpbc_set_device(i);
-            rc = bind_device();
-            if (rc == GPBC_OK && !d_part[i]) {
-                if (hipMalloc((void **)&d_part[i], pt) != hipSuccess || hipMemset(d_part[i], 0, pt) != hipSuccess) rc = fail(GPBC_ERR_HIP, "hipMalloc of a partial sum failed");
-            }
-            if (rc == GPBC_OK && hipMalloc((void **)&d_all[i], (size_t)nd * pt) != hipSuccess) rc = fail(GPBC_ERR_HIP, "hipMalloc of the gathered partial sums failed");
-        }
-        if (rc == GPBC_OK) rc = gpbc_allgather_all_dev((const void *const *)d_part.data(), pt, (void *const *)d_all.data(), nullptr);
-        (void)gpbc_set_device(0);
-        if (rc == GPBC_OK) rc = bind_device();
-        if (rc == GPBC_OK && hipStreamSynchronize(nullptr) != hipSuccess) rc = fail(GPBC_ERR_HIP, "hipStreamSynchronize failed after the all-gather");
-        if (rc == GPBC_OK && hipMemcpy(parts.data(), d_all[0], (size_t)nd * pt, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(GPBC_ERR_HIP, "download of the gathered partial sums failed");
-    }
-    release();
-    if (before >= 0) (void)gpbc_set_device(before);
-    if (rc != GPBC_OK) return rc;
+        return dp.download(parts.data() + (size_t)idx * pt, pt);
+    }));
     if (used.load() == 1) { memcpy(out, parts.data() + (size_t)(before > 0 && before < nd ? before : 0) * pt, pt); return GPBC_OK; }
-    return sum_one(g2, parts.data(), (size_t)nd, out);               // rows of devices without a shard are the point at infinity
+    return sum_one(g2, parts.data(), (size_t)nd, out);
 }
 static int sum_host(bool g2, const void *pts, size_t n, void *out) {
     if (!out || (n && !pts)) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
@@ -364,9 +331,9 @@ static int scalar_mul_sum_host(bool g2, const void *bases, const void *scalars, 
         DevBuf dB, dS, dM, dW;
         TRY(dB.upload((const uint8_t *)bases + lo * pt, m * pt)); TRY(dS.upload((const uint8_t *)scalars + lo * GPBC_SCALAR_BYTES, m * GPBC_SCALAR_BYTES));
         if (m >= MSM_MIN_TERMS) {                                  // bucket method instead of m independent multiplications
-            TRY(msm_dev(g2, dB.p, dS.p, m, d_out, nullptr));
-            return sync_default();
-        }
+            const int rc = msm_dev(g2, dB.p, dS.p, m, d_out, nullptr);
+            if (rc != MSM_SKEWED) { TRY(rc); return sync_default(); }
+        }                                                          // (skewed scalars: term by term, below)
         TRY(dM.alloc(m * pt));
         TRY(scalar_mul_dev(g2, dB.p, m, dS.p, m, dM.p, nullptr));
         const size_t wsb = gpbc_sum_workspace_bytes(m, g2);
@@ -384,20 +351,27 @@ static int scalar_mul_sum_dev(bool g2, const void *d_bases, const void *d_scalar
     hipStream_t st = (hipStream_t)stream;
     const size_t pt = g2 ? GPBC_G2_BYTES : GPBC_G1_BYTES;
     const int ranks = comm_ranks();
-    const bool bucket = n >= MSM_MIN_TERMS;                       // Pippenger instead of n independent multiplications + a sum tree
-    const size_t wsb_local = bucket ? 0 : gpbc_sum_workspace_bytes(n, g2), wsb_all = gpbc_sum_workspace_bytes((size_t)(ranks > 1 ? ranks : 1), g2);
-    // one stream-ordered scratch block: products | local tree workspace | local sum | gathered sums | final tree workspace
-    const size_t total = (bucket ? 0 : n * pt) + wsb_local + pt + (size_t)(ranks > 1 ? ranks : 1) * pt + wsb_all;
+    bool bucket = n >= MSM_MIN_TERMS;                             // Pippenger instead of n independent multiplications + a sum tree
+    const size_t wsb_all = gpbc_sum_workspace_bytes((size_t)(ranks > 1 ? ranks : 1), g2);
     Scratch tmp;                                                   // level 1: msm_dev and the shared-base path use level 0 underneath
-    TRY(tmp.open(st, 1, total));
-    uint8_t *mem = tmp.base;
-    uint8_t *prod = mem, *ws1 = prod + (bucket ? 0 : n * pt), *local = ws1 + wsb_local, *all = local + pt, *ws2 = all + (size_t)(ranks > 1 ? ranks : 1) * pt;
+    uint8_t *local = nullptr, *all = nullptr, *ws2 = nullptr;
     int rc = GPBC_OK;
-    uint8_t *local_out = ranks > 1 ? local : (uint8_t *)d_out;
-    if (bucket) rc = msm_dev(g2, d_bases, d_scalars, n, local_out, st);
-    else {
-        if (n) rc = scalar_mul_dev(g2, d_bases, n, d_scalars, n, prod, stream);
-        if (rc == GPBC_OK) rc = sum_dev(g2, prod, n, local_out, ws1, wsb_local, stream);
+    for (;;) {
+        // one stream-ordered scratch block: products | local tree workspace | local sum | gathered sums | final tree workspace
+        const size_t wsb_local = bucket ? 0 : gpbc_sum_workspace_bytes(n, g2);
+        const size_t total = (bucket ? 0 : n * pt) + wsb_local + pt + (size_t)(ranks > 1 ? ranks : 1) * pt + wsb_all;
+        TRY(tmp.open(st, 1, total));
+        uint8_t *prod = tmp.base, *ws1 = prod + (bucket ? 0 : n * pt);
+        local = ws1 + wsb_local; all = local + pt; ws2 = all + (size_t)(ranks > 1 ? ranks : 1) * pt;
+        uint8_t *local_out = ranks > 1 ? local : (uint8_t *)d_out;
+        if (bucket) {
+            rc = msm_dev(g2, d_bases, d_scalars, n, local_out, st);
+            if (rc == MSM_SKEWED) { bucket = false; continue; }    // skewed scalars: term by term
+        } else {
+            if (n) rc = scalar_mul_dev(g2, d_bases, n, d_scalars, n, prod, stream);
+            if (rc == GPBC_OK) rc = sum_dev(g2, prod, n, local_out, ws1, wsb_local, stream);
+        }
+        break;
     }
     if (rc == GPBC_OK && ranks > 1) {
         rc = comm_allgather(local, pt, all, st);

@@ -44,6 +44,17 @@ __global__ void __launch_bounds__(BLOCK) k_msm_keys(const uint8_t *__restrict__ 
     }
 }
 
+// the longest bucket: one lane adds a whole bucket serially (k_msm_buckets), so its length is the depth of the bucket stage
+__global__ void __launch_bounds__(SCAN_BLOCK) k_msm_max_count(const uint32_t *__restrict__ counts, size_t M, uint32_t *__restrict__ out) {
+    __shared__ uint32_t sh;
+    if (threadIdx.x == 0) sh = 0;
+    __syncthreads();
+    const size_t key = (size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
+    if (key < M && counts[key]) atomicMax(&sh, counts[key]);
+    __syncthreads();
+    if (threadIdx.x == 0 && sh) atomicMax(out, sh);
+}
+
 // exclusive scan of m counters: per-tile scan + tile totals, scan of the totals (one block), add-back
 __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_tiles(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint32_t *__restrict__ tile_sum, size_t m) {
     __shared__ uint32_t sh[SCAN_BLOCK];
@@ -236,6 +247,18 @@ template <class F> static int msm_run(const uint8_t *d_bases, const uint8_t *d_s
     auto step = [&](const char *name) { if (rc == GPBC_OK) { rc = check_launch(name); profile_mark(name, st); } };
     if (hipMemsetAsync(counts, 0, p.M * 4, st) != hipSuccess) rc = fail(GPBC_ERR_HIP, "hipMemsetAsync failed");
     if (rc == GPBC_OK) { k_msm_keys<F, false><<<grid_for(n), BLOCK, 0, st>>>(d_bases, d_scalars, n, p.c, p.W, counts, nullptr, nullptr); step(G2 ? "k_msm_count_g2" : "k_msm_count_g1"); }
+    // Skewed scalars (all rho equal, small integers, one repeated value): a window's terms land in ONE bucket, and the lane that owns
+    // it would run n dependent additions — seconds.  The histogram says so before any point is touched: when the longest bucket is far
+    // above the mean the caller takes the per-term path (n independent scalar multiplications + the sum tree: milliseconds).  Costs
+    // one 4-byte read-back and a host wait for the counting kernel (~20 us of a multi-millisecond call).
+    if (rc == GPBC_OK) {
+        uint8_t *pin = nullptr;
+        rc = pinned_staging(st, 4096, &pin);
+        if (rc == GPBC_OK && hipMemsetAsync(total, 0, 4, st) != hipSuccess) rc = fail(GPBC_ERR_HIP, "hipMemsetAsync failed");
+        if (rc == GPBC_OK) { k_msm_max_count<<<(unsigned)((p.M + SCAN_BLOCK - 1) / SCAN_BLOCK), SCAN_BLOCK, 0, st>>>(counts, p.M, total); step("k_msm_max_count"); }
+        if (rc == GPBC_OK && (hipMemcpyAsync(pin, total, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) rc = fail(GPBC_ERR_HIP, "read-back of the longest bucket failed");
+        if (rc == GPBC_OK && *(const uint32_t *)pin > MSM_MAX_BUCKET_BASE + 8 * (uint32_t)(n >> p.c)) return MSM_SKEWED;
+    }
     if (rc == GPBC_OK) { k_scan_tiles<<<(unsigned)n_tiles, SCAN_BLOCK, 0, st>>>(counts, offsets, tiles, p.M); step("k_scan_tiles"); }
     if (rc == GPBC_OK) { k_scan_tops<<<1, SCAN_BLOCK, 0, st>>>(tiles, n_tiles, total); step("k_scan_tops"); }
     if (rc == GPBC_OK) { k_scan_add<<<(unsigned)n_tiles, SCAN_BLOCK, 0, st>>>(offsets, tiles, p.M, total); step("k_scan_add"); }
@@ -264,7 +287,8 @@ template <class F> static int msm_run(const uint8_t *d_bases, const uint8_t *d_s
     return rc;
 }
 
-// sum_i [s_i] P_i over n >= MSM_MIN_TERMS terms in device memory, result (one affine point, gnark layout) at d_out
+// sum_i [s_i] P_i over n >= MSM_MIN_TERMS terms in device memory, result (one affine point, gnark layout) at d_out; MSM_SKEWED
+// (nothing written) when one bucket would be too long a chain — the caller then multiplies term by term
 int msm_dev(bool g2, const void *d_bases, const void *d_scalars, size_t n, void *d_out, hipStream_t st) {
     TRY(bind_device());
     return g2 ? msm_run<F2>((const uint8_t *)d_bases, (const uint8_t *)d_scalars, n, (uint8_t *)d_out, st)

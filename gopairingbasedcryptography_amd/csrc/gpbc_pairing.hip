@@ -33,9 +33,8 @@ __device__ __forceinline__ LineS line_load(const int32_t *__restrict__ buf, size
 // register): line s + 1 is requested as soon as line s has been read out of the stage, so its HBM latency passes behind the sparse
 // product and the next squaring instead of in front of the product (the compiler cannot hoist 54 register loads above six leaf
 // calls; an LDS stage costs no registers).  Each lane of a pair requests half of the 54 words — the even lane words 0..26, the odd
-// lane 27..53, one 256-byte LDS row per request — and both read all of them back.  -DGPBC_LINES_BY_REGISTER_LOADS is the previous
-// form (A/B runs).
-#ifndef GPBC_LINES_BY_REGISTER_LOADS
+// lane 27..53, one 256-byte LDS row per request — and both read all of them back.  (The register-load form it replaced measured
+// 55.4 against 54.6 ms, profiles/r02_variant_line_dma.txt; it lives in the history before round 3.)
 __shared__ int32_t g_line_stage[27][BLOCK];
 __device__ __forceinline__ void line_request(const int32_t *__restrict__ buf, size_t stride, size_t lane, int step, bool odd) {
     const int32_t *b = buf + ((size_t)step * LINE_WORDS + (odd ? 27 : 0)) * stride + lane;
@@ -52,7 +51,6 @@ __device__ __forceinline__ LineS line_from_stage() {
     __builtin_amdgcn_s_waitcnt(0xC07F);                          // lgkmcnt(0): read out before the next request may overwrite the stage
     return l;
 }
-#endif
 
 GPBC_KERNEL k_miller_lines(const uint8_t *__restrict__ P, const uint8_t *__restrict__ Q, int32_t *__restrict__ lines, size_t n, size_t stride) {
     size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -78,16 +76,12 @@ GPBC_KERNEL k_miller_accumulate(const uint8_t *__restrict__ P, const uint8_t *__
     if (g1_bytes_inf(p) || g2_bytes_inf(q)) h = f12p_one(x);
     else {
         int step = 0;
-#ifndef GPBC_LINES_BY_REGISTER_LOADS
         line_request(lines, stride, i, 0, x.odd);
         h = miller_accumulate_pair(x, [&]() -> LineS {
             LineS l = line_from_stage();
             if (++step < MILLER_LINES) line_request(lines, stride, i, step, x.odd);
             return l;
         });
-#else
-        h = miller_accumulate_pair(x, [&]() -> LineS { return line_load(lines, stride, i, step++); });
-#endif
     }
     f6_store(f_out + i * GPBC_GT_BYTES + (x.odd ? 192 : 0), h);
 }
@@ -156,13 +150,19 @@ GPBC_KERNEL k_miller_pipelined(const uint8_t *__restrict__ P, const uint8_t *__r
 // adjacent lane pairs read adjacent words whatever the chunk lengths are.
 constexpr int MULTI_CHUNK = 8;
 constexpr size_t MULTI_GROUP = 65536;
+// Both kernels ECHO the chunk bounds they read from the device copy of the host's table (`seen_lines`, `seen`: two words per
+// chunk) — k_segment_product folds the echo into "first pair, pairs consumed" per segment and the host entry compares that with
+// ITS table before it reports anything (multi_pair_core: a product over fewer pairs than the caller passed must never come back as
+// a result, least of all as "PairingCheck = true").
 GPBC_KERNEL k_miller_lines_chunks(const uint8_t *__restrict__ P, const uint8_t *__restrict__ Q, int32_t *__restrict__ lines,
-                                  const uint64_t *__restrict__ chunk_off, size_t n_chunks, size_t n_slots) {
+                                  const uint64_t *__restrict__ chunk_off, size_t n_chunks, size_t n_slots, uint64_t *__restrict__ seen_lines) {
     size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (t >= n_slots) return;
     const size_t i = t / n_chunks, c = t % n_chunks;
-    const uint64_t pair = chunk_off[c] + i;
-    if (pair >= chunk_off[c + 1]) return;                      // slot beyond this chunk's length
+    const uint64_t c_lo = chunk_off[c], c_hi = chunk_off[c + 1];
+    if (i == 0) { seen_lines[2 * c] = c_lo; seen_lines[2 * c + 1] = c_hi; }
+    const uint64_t pair = c_lo + i;
+    if (pair >= c_hi) return;                                  // slot beyond this chunk's length
     const uint8_t *p = P + pair * GPBC_G1_BYTES, *q = Q + pair * GPBC_G2_BYTES;
     if (g1_bytes_inf(p) || g2_bytes_inf(q)) return;
     G1A a{fe_load(p), fe_load(p + 32)};
@@ -171,12 +171,18 @@ GPBC_KERNEL k_miller_lines_chunks(const uint8_t *__restrict__ P, const uint8_t *
     miller_lines(a, b, [&](const LineS &l) { line_store(lines, n_slots, t, step++, l); });
 }
 GPBC_KERNEL k_miller_accumulate_chunks(const uint8_t *__restrict__ P, const uint8_t *__restrict__ Q, const int32_t *__restrict__ lines,
-                                       const uint64_t *__restrict__ chunk_off, uint8_t *__restrict__ f_out, size_t n_chunks, size_t n_slots) {
+                                       const uint64_t *__restrict__ chunk_off, uint8_t *__restrict__ f_out, size_t n_chunks, size_t n_slots,
+                                       const uint64_t *__restrict__ seen_lines, uint64_t *__restrict__ seen) {
     size_t lane = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     size_t c = lane >> 1;
     if (c >= n_chunks) return;
     PairDpp x{(bool)(lane & 1)};
     const uint64_t lo = chunk_off[c], hi = chunk_off[c + 1];
+    if (!x.odd) {                                              // the bounds THIS kernel used; poisoned if the line phase used others
+        const bool same = seen_lines[2 * c] == lo && seen_lines[2 * c + 1] == hi && hi >= lo && hi - lo <= (uint64_t)MULTI_CHUNK;
+        seen[2 * c] = same ? lo : ~0ull;
+        seen[2 * c + 1] = same ? hi : 0;
+    }
     int vi[MULTI_CHUNK], m = 0;                                // positions of the pairs that have no point at infinity
     for (uint64_t i = 0; i < hi - lo && i < (uint64_t)MULTI_CHUNK; i++)
         if (!g1_bytes_inf(P + (lo + i) * GPBC_G1_BYTES) && !g2_bytes_inf(Q + (lo + i) * GPBC_G2_BYTES)) vi[m++] = (int)i;
@@ -286,19 +292,33 @@ GPBC_KERNEL k_final_exp(const uint8_t *f_in, uint8_t *gt_out, size_t n) {
 
 // product of the Miller functions of each segment: thread j multiplies f[seg_off[j] .. seg_off[j+1])
 // (the segment table lives in device memory and cannot be validated by the host without a copy: offsets are clamped to
-// the number of pairs so that a malformed table can never read outside the Miller-value buffer)
-GPBC_KERNEL k_segment_product(const uint8_t *__restrict__ f, const uint64_t *__restrict__ seg_off, uint8_t *__restrict__ out, size_t k, size_t n_pairs) {
+// the number of values so that a malformed table can never read outside the Miller-value buffer).
+// `echo` (two words per segment, may be null): what this thread actually consumed — the first pair index and the number of pairs.
+// With `seen` null the values are single Miller values and the echo is the table entry as used; with `seen` the values are chunk
+// products and the echo is folded from the bounds k_miller_accumulate_chunks recorded per chunk (count ~0 if the chunks of the
+// segment were not contiguous).  The host-table entries compare the echo with the table they copied (multi_pair_core).
+GPBC_KERNEL k_segment_product(const uint8_t *__restrict__ f, const uint64_t *__restrict__ seg_off, uint8_t *__restrict__ out, size_t k, size_t n_vals,
+                              const uint64_t *__restrict__ seen, uint64_t *__restrict__ echo) {
     size_t j = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (j >= k) return;
     F12 acc = f12_one(), t;
     uint64_t lo = seg_off[j], hi = seg_off[j + 1];
-    if (hi > n_pairs) hi = n_pairs;
+    if (hi > n_vals) hi = n_vals;
     if (lo > hi) lo = hi;
+    uint64_t first = lo, count = hi - lo;
+    if (seen) {
+        first = lo < hi ? seen[2 * lo] : 0;
+        uint64_t expect = first;
+        bool contiguous = true;
+        for (uint64_t i = lo; i < hi; i++) { contiguous = contiguous && seen[2 * i] == expect && seen[2 * i + 1] >= expect; expect = seen[2 * i + 1]; }
+        count = contiguous ? expect - first : ~0ull;
+    }
     for (uint64_t i = lo; i < hi; i++) {
         f12_load(t, f + i * GPBC_GT_BYTES);
         acc = f12_mul(acc, t);
     }
     f12_store(out + j * GPBC_GT_BYTES, acc);
+    if (echo) { echo[2 * j] = first; echo[2 * j + 1] = count; }
 }
 
 // the same product over equal runs of n_c values per output (fixed-Q multi-pairing: no table needed)
@@ -420,16 +440,20 @@ int gpbc_pair_batch_dev(const void *dP, const void *dQ, size_t n, void *d_gt_out
     return gpbc_final_exp_dev(d_gt_out, n, d_gt_out, stream);      // each lane rewrites its own 384 B
 }
 size_t gpbc_multi_pair_workspace_bytes(size_t n_pairs, size_t k) { (void)k; return n_pairs * GPBC_GT_BYTES; }
-int gpbc_multi_pair_dev(const void *dP, const void *dQ, const uint64_t *d_seg_off, size_t n_pairs, size_t k,
-                        void *d_gt_out, void *d_workspace, size_t workspace_bytes, void *stream) {
+static int multi_pair_dev_echo(const void *dP, const void *dQ, const uint64_t *d_seg_off, size_t n_pairs, size_t k,
+                               void *d_gt_out, void *d_workspace, size_t workspace_bytes, uint64_t *d_echo, void *stream) {
     if (!k) return fail(GPBC_ERR_INVALID_ARG, "invalid inputs sizes");
     if (!d_seg_off || !d_gt_out || (n_pairs && (!dP || !dQ || !d_workspace))) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
     if (workspace_bytes < gpbc_multi_pair_workspace_bytes(n_pairs, k)) return fail(GPBC_ERR_WORKSPACE, "workspace too small");
     TRY(gpbc_miller_loop_dev(dP, dQ, n_pairs, d_workspace, stream));
-    k_segment_product<<<grid_for(k), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_workspace, d_seg_off, (uint8_t *)d_gt_out, k, n_pairs);
+    k_segment_product<<<grid_for(k), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_workspace, d_seg_off, (uint8_t *)d_gt_out, k, n_pairs, nullptr, d_echo);
     TRY(check_launch("k_segment_product"));
     profile_mark("k_segment_product", (hipStream_t)stream);
     return gpbc_final_exp_dev(d_gt_out, k, d_gt_out, stream);
+}
+int gpbc_multi_pair_dev(const void *dP, const void *dQ, const uint64_t *d_seg_off, size_t n_pairs, size_t k,
+                        void *d_gt_out, void *d_workspace, size_t workspace_bytes, void *stream) {
+    return multi_pair_dev_echo(dP, dQ, d_seg_off, n_pairs, k, d_gt_out, d_workspace, workspace_bytes, nullptr, stream);
 }
 int gpbc_check_segments_dev(const uint64_t *d_seg_off, size_t n_pairs, size_t k, void *stream) {
     if (!k) return fail(GPBC_ERR_INVALID_ARG, "invalid inputs sizes");
@@ -570,6 +594,25 @@ int gpbc_set_multi_pair_chunk(int pairs_per_chunk) {
     g_multi_chunk.store(pairs_per_chunk);
     return GPBC_OK;
 }
+// The product of a segment is only as good as the table the kernels read.  Round 2 recorded a verifier that answered "true" for a
+// forged signature because k_segment_product had seen an EMPTY segment where the host's table said two pairs
+// (profiles/r02_pool_bisect.txt; DESIGN.md §4 names the unordered operation).  The invariant since: (1) host tables travel through
+// library-owned PINNED staging memory (pinned_staging: one buffer per device and stream, held under the scratch lock until the
+// call has synchronised), so the copy is a stream-ordered DMA from memory nobody else writes; (2) the kernels echo what they
+// consumed and the call FAILS (GPBC_ERR_INTERNAL, outputs zeroed) unless that equals the host's table segment by segment.
+// test knob: the NEXT host-table multi-pairing sends the device a table whose last segment is empty while the host keeps the real
+// one — what a stale or unordered table copy looks like to the kernels; the call must then fail (tests/cpp/test_bls_flow.cpp)
+static std::atomic<int> g_fault_table{0};
+int gpbc_debug_stale_table_once(void) { g_fault_table.store(1); return GPBC_OK; }
+static int verify_echo(const uint64_t *echo, const uint64_t *seg_off, size_t k) {
+    for (size_t j = 0; j < k; j++) {
+        const uint64_t want = seg_off[j + 1] - seg_off[j];
+        if (echo[2 * j + 1] != want || (want && echo[2 * j] != seg_off[j]))
+            return fail(GPBC_ERR_INTERNAL, "segment %zu: the device consumed %llu pairs from %llu, the host table says %llu from %llu — result withheld", j,
+                        (unsigned long long)echo[2 * j + 1], (unsigned long long)echo[2 * j], (unsigned long long)want, (unsigned long long)seg_off[j]);
+    }
+    return GPBC_OK;
+}
 static int multi_pair_core(const uint8_t *dP, const uint8_t *dQ, const uint64_t *seg_off, size_t k, size_t n_pairs, uint8_t *dG, uint8_t *dOk, hipStream_t st) {
     // Chunk length L: as long as possible (more shared squarings) while ~131072 lane pairs stay in flight, and at most
     // MULTI_CHUNK; with at least 65536 segments that all fit a chunk (AFP25: 3 pairs, BLS checks: 2) a chunk is a whole
@@ -582,42 +625,51 @@ static int multi_pair_core(const uint8_t *dP, const uint8_t *dQ, const uint64_t 
     uint64_t L = (n_pairs + 131071) / 131072;
     if (max_len <= (uint64_t)MULTI_CHUNK) L = k >= MULTI_GROUP ? max_len : 1;      // short segments: whole or not at all
     if (g_multi_chunk.load() > 0) L = (uint64_t)g_multi_chunk.load();                 // (capped at MULTI_CHUNK below)
+    const size_t echo_bytes = 2 * k * sizeof(uint64_t);
+    Scratch tmp;                     // held until the stream has been synchronised: the pinned staging below belongs to this call until then
+    uint64_t *h_echo = nullptr, *dEcho = nullptr;
+    int rc = GPBC_OK;
     if (L <= 1 && g_multi_chunk.load() <= 0) {
         // nothing to share (few pairs, or single-pair segments): one Miller loop per lane pair and one product per segment
-        {
-            const size_t wsb = gpbc_multi_pair_workspace_bytes(n_pairs, k), seg_bytes = (k + 1) * sizeof(uint64_t);
-            Scratch tmp;
-            TRY(tmp.open(st, 0, Scratch::padded(seg_bytes) + Scratch::padded(wsb)));
-            uint64_t *dSeg = tmp.take<uint64_t>(seg_bytes);
-            uint8_t *dW = tmp.take(wsb);
-            HIP_TRY(hipMemcpyAsync(dSeg, seg_off, seg_bytes, hipMemcpyHostToDevice, st));
-            TRY(gpbc_multi_pair_dev(dP, dQ, dSeg, n_pairs, k, dG, dW, wsb, st));
-            if (dOk) {
-                k_gt_is_one<<<grid_for(k), BLOCK, 0, st>>>(dG, dOk, k);
-                TRY(check_launch("k_gt_is_one"));
-                profile_mark("k_gt_is_one", st);
-            }
+        const size_t wsb = gpbc_multi_pair_workspace_bytes(n_pairs, k), seg_bytes = (k + 1) * sizeof(uint64_t);
+        TRY(tmp.open(st, 0, Scratch::padded(seg_bytes) + Scratch::padded(echo_bytes) + Scratch::padded(wsb)));
+        uint64_t *dSeg = tmp.take<uint64_t>(seg_bytes);
+        dEcho = tmp.take<uint64_t>(echo_bytes);
+        uint8_t *dW = tmp.take(wsb);
+        uint8_t *pin = nullptr;
+        TRY(pinned_staging(st, Scratch::padded(seg_bytes) + echo_bytes, &pin));
+        memcpy(pin, seg_off, seg_bytes);
+        if (g_fault_table.exchange(0)) ((uint64_t *)pin)[k] = ((uint64_t *)pin)[k - 1];
+        h_echo = (uint64_t *)(pin + Scratch::padded(seg_bytes));
+        HIP_TRY(hipMemcpyAsync(dSeg, pin, seg_bytes, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemsetAsync(dEcho, 0xff, echo_bytes, st));
+        TRY(multi_pair_dev_echo(dP, dQ, dSeg, n_pairs, k, dG, dW, wsb, dEcho, st));
+    } else {
+        if (L < 1) L = 1;
+        if (L > (uint64_t)MULTI_CHUNK) L = MULTI_CHUNK;
+        std::vector<uint64_t> chunk_off(1, 0), seg_chunk(1, 0);
+        for (size_t j = 0; j < k; j++) {
+            for (uint64_t a = seg_off[j]; a < seg_off[j + 1]; a += L)
+                chunk_off.push_back(a + L < seg_off[j + 1] ? a + L : seg_off[j + 1]);
+            seg_chunk.push_back(chunk_off.size() - 1);
         }
-        HIP_TRY(hipStreamSynchronize(st));
-        return GPBC_OK;
-    }
-    if (L < 1) L = 1;
-    if (L > (uint64_t)MULTI_CHUNK) L = MULTI_CHUNK;
-    std::vector<uint64_t> chunk_off(1, 0), seg_chunk(1, 0);
-    for (size_t j = 0; j < k; j++) {
-        for (uint64_t a = seg_off[j]; a < seg_off[j + 1]; a += L)
-            chunk_off.push_back(a + L < seg_off[j + 1] ? a + L : seg_off[j + 1]);
-        seg_chunk.push_back(chunk_off.size() - 1);
-    }
-    const size_t n_chunks = chunk_off.size() - 1;
-    {
-        const size_t co_bytes = chunk_off.size() * sizeof(uint64_t), sc_bytes = seg_chunk.size() * sizeof(uint64_t);
-        Scratch tmp;
-        TRY(tmp.open(st, 0, Scratch::padded(co_bytes) + Scratch::padded(sc_bytes) + Scratch::padded(n_chunks * GPBC_GT_BYTES)));
+        const size_t n_chunks = chunk_off.size() - 1;
+        const size_t co_bytes = chunk_off.size() * sizeof(uint64_t), sc_bytes = seg_chunk.size() * sizeof(uint64_t), seen_bytes = 2 * (n_chunks + 1) * sizeof(uint64_t);
+        TRY(tmp.open(st, 0, Scratch::padded(co_bytes) + Scratch::padded(sc_bytes) + 2 * Scratch::padded(seen_bytes) + Scratch::padded(echo_bytes) + Scratch::padded(n_chunks * GPBC_GT_BYTES)));
         uint64_t *dChunkOff = tmp.take<uint64_t>(co_bytes), *dSegChunk = tmp.take<uint64_t>(sc_bytes);
+        uint64_t *dSeenLines = tmp.take<uint64_t>(seen_bytes), *dSeen = tmp.take<uint64_t>(seen_bytes);
+        dEcho = tmp.take<uint64_t>(echo_bytes);
         uint8_t *dPart = tmp.take(n_chunks * GPBC_GT_BYTES);
-        HIP_TRY(hipMemcpyAsync(dChunkOff, chunk_off.data(), co_bytes, hipMemcpyHostToDevice, st));   // the vectors outlive the
-        HIP_TRY(hipMemcpyAsync(dSegChunk, seg_chunk.data(), sc_bytes, hipMemcpyHostToDevice, st));   // synchronisation below
+        uint8_t *pin = nullptr;
+        TRY(pinned_staging(st, Scratch::padded(co_bytes) + Scratch::padded(sc_bytes) + echo_bytes, &pin));
+        memcpy(pin, chunk_off.data(), co_bytes);
+        memcpy(pin + Scratch::padded(co_bytes), seg_chunk.data(), sc_bytes);
+        if (g_fault_table.exchange(0)) ((uint64_t *)(pin + Scratch::padded(co_bytes)))[k] = ((uint64_t *)(pin + Scratch::padded(co_bytes)))[k - 1];
+        h_echo = (uint64_t *)(pin + Scratch::padded(co_bytes) + Scratch::padded(sc_bytes));
+        HIP_TRY(hipMemcpyAsync(dChunkOff, pin, co_bytes, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(dSegChunk, pin + Scratch::padded(co_bytes), sc_bytes, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemsetAsync(dSeenLines, 0xff, seen_bytes, st));
+        HIP_TRY(hipMemsetAsync(dEcho, 0xff, echo_bytes, st));
         std::lock_guard<std::mutex> seq(g_ws_seq_mu);
         // the line phase runs one lane per pair: with an odd chunk length a group of 65 536 chunks fills an odd number of half
         // rounds of the chip (3 pairs: 1.5 rounds, i.e. two) — two groups at a time make it whole (3 rounds for 131 072 chunks)
@@ -630,25 +682,32 @@ static int multi_pair_core(const uint8_t *dP, const uint8_t *dQ, const uint64_t 
             int32_t *lines = nullptr;
             TRY(lines_workspace(st, n_slots, &lines));
             const uint64_t *co = dChunkOff + cb;
-            k_miller_lines_chunks<<<grid_for(n_slots), BLOCK, 0, st>>>(dP, dQ, lines, co, g, n_slots);
+            k_miller_lines_chunks<<<grid_for(n_slots), BLOCK, 0, st>>>(dP, dQ, lines, co, g, n_slots, dSeenLines + 2 * cb);
             TRY(check_launch("k_miller_lines_chunks"));
             profile_mark("k_miller_lines_chunks", st);
-            k_miller_accumulate_chunks<<<grid_for(2 * g), BLOCK, 0, st>>>(dP, dQ, lines, co, dPart + cb * GPBC_GT_BYTES, g, n_slots);
+            k_miller_accumulate_chunks<<<grid_for(2 * g), BLOCK, 0, st>>>(dP, dQ, lines, co, dPart + cb * GPBC_GT_BYTES, g, n_slots, dSeenLines + 2 * cb, dSeen + 2 * cb);
             TRY(check_launch("k_miller_accumulate_chunks"));
             profile_mark("k_miller_accumulate_chunks", st);
         }
-        k_segment_product<<<grid_for(k), BLOCK, 0, st>>>(dPart, dSegChunk, dG, k, n_chunks);
+        k_segment_product<<<grid_for(k), BLOCK, 0, st>>>(dPart, dSegChunk, dG, k, n_chunks, dSeen, dEcho);
         TRY(check_launch("k_segment_product (segments)"));
         profile_mark("k_segment_product", st);
+        TRY(gpbc_final_exp_dev(dG, k, dG, st));
     }
-    TRY(gpbc_final_exp_dev(dG, k, dG, st));
     if (dOk) {
         k_gt_is_one<<<grid_for(k), BLOCK, 0, st>>>(dG, dOk, k);
         TRY(check_launch("k_gt_is_one"));
         profile_mark("k_gt_is_one", st);
     }
+    HIP_TRY(hipMemcpyAsync(h_echo, dEcho, echo_bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    return GPBC_OK;
+    rc = verify_echo(h_echo, seg_off, k);
+    if (rc != GPBC_OK) {                                    // fail closed: nothing computed from a table that was not the caller's leaves this call
+        (void)hipMemsetAsync(dG, 0, k * GPBC_GT_BYTES, st);
+        if (dOk) (void)hipMemsetAsync(dOk, 0, k, st);
+        (void)hipStreamSynchronize(st);
+    }
+    return rc;
 }
 // out[j] = Pair(P[j*m .. (j+1)*m), Q[0 .. m)), j < k.  Asynchronous on the stream (its temporaries live in the stream's scratch).
 int gpbc_multi_pair_fixed_q_dev(const void *dP, const void *dQ, size_t m, size_t k, void *d_gt_out, void *stream) {

@@ -219,7 +219,7 @@ static int hash_dev(int what, const void *d_msgs, const uint64_t *d_off, size_t 
     TRY(bind_device());
     XmdDst d;
     memset(&d, 0, sizeof d);
-    memcpy(d.b, dst, dst_len);
+    if (dst_len) memcpy(d.b, dst, dst_len);                      // dst == NULL with dst_len == 0 is a legal (empty) tag
     d.len = (uint32_t)dst_len;
     hipStream_t st = (hipStream_t)stream;
     const uint8_t *m = (const uint8_t *)d_msgs;

@@ -55,7 +55,7 @@ template <bool NORM> GPBC_INLINE F2 f2_sqr_core(const F2 &xx) {
     fe_sqrdiff_mul_dual(r.a0, r.a1, x.a0, x.a1);          // (a0^2 - a1^2, 2 a0 a1) without the operand sums
     return r;
 }
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(GPBC_BOUNDS) && !defined(GPBC_INLINE_LEAVES)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GPBC_BOUNDS)
 // F2-level leaves: one call per F2 product / squaring, all 36 / 18 limbs as scalar arguments (VGPRs; the last few of
 // the 36 travel through the stack), the 18 result limbs returned in registers as one vector value.
 typedef int32_t i32x18 __attribute__((ext_vector_type(18)));
@@ -79,15 +79,7 @@ GPBC_INLINE F2 f2_from_vec(const i32x18 &v) {
 // half of the kernel's traffic.  They go through LDS instead: a 16-byte and a 4-byte slot per lane of the (64-thread) workgroup,
 // written by the caller right before the call and read first thing by the leaf, in order on the wave's LDS queue.  The slot is
 // addressed by the lane number from v_mbcnt (= threadIdx.x of a one-wave workgroup).
-// -DGPBC_F2_ARGS_ON_STACK restores the stack form for A/B measurements (tools/variant_bench.sh).
-#ifdef GPBC_F2_ARGS_ON_STACK
-template <bool NORM> __device__ __noinline__ i32x18 f2_mul_leaf(GPBC_ARGS9(a), GPBC_ARGS9(b), GPBC_ARGS9(c), GPBC_ARGS9(d)) {
-    return f2_to_vec(f2_mul_core<NORM>(GPBC_PACK_F2(a, b), GPBC_PACK_F2(c, d)));
-}
-template <bool NORM> GPBC_INLINE F2 f2_mul_call(const F2 &x, const F2 &y) {
-    return f2_from_vec(f2_mul_leaf<NORM>(GPBC_PASS9(x.a0), GPBC_PASS9(x.a1), GPBC_PASS9(y.a0), GPBC_PASS9(y.a1)));
-}
-#else
+// (The stack form measured 57.5 against 55.1 ms on k_miller_accumulate: profiles/r02_variant_lds_args.txt.)
 typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
 __shared__ i32x4 g_f2_arg_slot[64];
 __shared__ int32_t g_f2_arg_slot4[64];
@@ -104,7 +96,6 @@ template <bool NORM> GPBC_INLINE F2 f2_mul_call(const F2 &x, const F2 &y) {
     g_f2_arg_slot4[lane] = y.a1.v[4];
     return f2_from_vec(f2_mul_leaf<NORM>(GPBC_PASS9(x.a0), GPBC_PASS9(x.a1), GPBC_PASS9(y.a0), y.a1.v[0], y.a1.v[1], y.a1.v[2], y.a1.v[3]));
 }
-#endif
 template <bool NORM> __device__ __noinline__ i32x18 f2_sqr_leaf(GPBC_ARGS9(a), GPBC_ARGS9(b)) {
     return f2_to_vec(f2_sqr_core<NORM>(GPBC_PACK_F2(a, b)));
 }

@@ -132,8 +132,8 @@ template <class X> GPBC_INLINE F6 f12p_mul_034_by_034(const X &x, const F2 &c0, 
 // transaction on this machine, LDS does not.  Used where a value is computed early and needed only at the end of a
 // long stretch of leaf calls, during which just ~158 VGPRs survive a call (the leaf itself takes 98).  Layout [chunk of 4 limbs]
 // [lane]: 14 ds_write_b128 / ds_read_b128, conflict-free.  The host build of the bounds harness keeps the object (with its
-// intervals) as it is.  -DGPBC_NO_F6_PARK keeps the value in registers (A/B runs).  One slot: parked values must not nest.
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(GPBC_BOUNDS) && !defined(GPBC_INLINE_LEAVES) && !defined(GPBC_F2_ARGS_ON_STACK) && !defined(GPBC_NO_F6_PARK)
+// intervals) as it is.  One slot: parked values must not nest.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GPBC_BOUNDS)
 __shared__ i32x4 g_f6_park[14][64];
 struct F6Park {
     GPBC_INLINE explicit F6Park(const F6 &v) {

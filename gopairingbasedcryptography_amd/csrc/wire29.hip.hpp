@@ -117,10 +117,8 @@ GPBC_INLINE Fe fe_sqrt(const Fe &a, bool &ok) {
 // is_square in Fp: the divstep-based Legendre symbol (fe29.hip.hpp), the power a^((p-1)/2) where that does not decide; 0 counts as
 // a square (RFC 9380)
 GPBC_INLINE bool fe_is_square(const Fe &a) {
-#ifndef GPBC_IS_SQUARE_BY_POWER
     const int j = fe_legendre(a);
     if (j) return j > 0;
-#endif
     constexpr int32_t E12[NL] = F29_EXP_P12;
     Fe l = g_pow_limbs(a, E12);
     return !fe_is_zero(fe_norm(fe_add(l, fe_one())));
@@ -129,8 +127,7 @@ GPBC_INLINE bool fe_is_square(const Fe &a) {
 // (a0 + s) / 2 and (a0 - s) / 2 is a square in Fp (their product is -a1^2 / 4), the Legendre symbol says which, x0 is its root
 // and x1 = a1 / (2 x0).  Two Fp powers, one symbol and one safegcd inversion (~170 k instructions) in place of the two Fp2 powers
 // of the complex method below (~340 k).  Either root serves: every caller fixes the sign afterwards (sgn0 / the wire flag).
-// -DGPBC_F2_SQRT_COMPLEX selects the previous form (A/B runs).
-#ifndef GPBC_F2_SQRT_COMPLEX
+// (profiles/r02_variant_f2_sqrt.txt has the A/B run against the complex method.)
 GPBC_INLINE F2 f2_sqrt(const F2 &a, bool &ok) {
     F2 x;
     if (fe_is_zero(fe_norm(a.a1))) {                             // a in Fp: sqrt(a0), or i sqrt(-a0) (-1 is not a square)
@@ -150,22 +147,6 @@ GPBC_INLINE F2 f2_sqrt(const F2 &a, bool &ok) {
     ok = g_equal(f2_sqr(x), a);
     return x;
 }
-#else
-// Fp2, complex method (Adj, Rodriguez-Henriquez, "Square root computation over even extension fields", Alg. 9):
-// a1 = a^((p-3)/4), x0 = a1 a, alpha = a1 x0; alpha = -1 -> i x0, else (1 + alpha)^((p-1)/2) x0
-GPBC_INLINE F2 f2_sqrt(const F2 &a, bool &ok) {
-    constexpr int32_t E34[NL] = F29_EXP_P34, E12[NL] = F29_EXP_P12;
-    F2 a1 = g_pow_limbs(a, E34);
-    F2 x0 = f2_mul(a1, a);
-    F2 alpha = f2_mul(a1, x0);
-    F2 ap1 = f2_norm(f2_add(alpha, f2_one()));
-    F2 x;
-    if (f2_is_zero(ap1)) x = F2{fe_neg(x0.a1), x0.a0};
-    else x = f2_mul(g_pow_limbs(ap1, E12), x0);
-    ok = g_equal(f2_sqr(x), a);
-    return x;
-}
-#endif
 
 // ---- coordinates <-> bytes
 GPBC_INLINE bool fe_wire_load(Fe &r, const uint8_t *p, uint8_t first_mask, bool &zero) {

@@ -20,6 +20,8 @@ import "C"
 import (
 	"errors"
 	"math/big"
+	"runtime"
+	"sync"
 	"unsafe"
 
 	"github.com/consensys/gnark-crypto/ecc/bn254"
@@ -28,6 +30,14 @@ import (
 )
 
 var errSizes = errors.New("invalid inputs sizes") // gnark's own error text for Pair / PairingCheck
+
+// gpbc_last_error() is thread-local on the C side and a goroutine may move to another OS thread between two cgo calls, so
+// every exported function pins its goroutine for the length of the call (`defer pin()()` first thing): the status of a
+// library call and the message that belongs to it are then read on the same thread.
+func pin() func() {
+	runtime.LockOSThread()
+	return runtime.UnlockOSThread
+}
 
 func status(rc C.int) error {
 	if rc == 0 {
@@ -45,6 +55,7 @@ func must(rc C.int) {
 // Init binds the process to the given HIP devices (nil or empty: every visible device).  Host-slice batch calls then
 // shard their index range over all of them inside the library; results do not depend on the number of devices.
 func Init(devices []int) error {
+	defer pin()()
 	if len(devices) == 0 {
 		n := int(C.gpbc_device_count())
 		if n <= 0 {
@@ -66,14 +77,21 @@ func NumDevices() int { return int(C.gpbc_num_devices()) }
 
 // InitCollectives opens one RCCL communicator over the bound devices: the partial sums of G1ScalarMulSum / G2ScalarMulSum
 // are then exchanged by ncclAllGather over xGMI instead of through the host.
-func InitCollectives() error { return status(C.gpbc_comm_init_all()) }
+func InitCollectives() error {
+	defer pin()()
+	return status(C.gpbc_comm_init_all())
+}
 
 // Shutdown releases the library's device memory and communicators.
-func Shutdown() error { return status(C.gpbc_shutdown()) }
+func Shutdown() error {
+	defer pin()()
+	return status(C.gpbc_shutdown())
+}
 
 // Pair replaces bn254.Pair (cpabe/bsw07/bsw07_cpabe.go:75,184; access/tree/access_tree_node.go:106,110,119;
 // bibe/afp25_bibe/afp25_bibe.go:227,395,399,403; ...): product of pairings, one final exponentiation.
 func Pair(P []bn254.G1Affine, Q []bn254.G2Affine) (bn254.GT, error) {
+	defer pin()()
 	var gt bn254.GT
 	if len(P) == 0 || len(P) != len(Q) {
 		return gt, errSizes
@@ -86,6 +104,7 @@ func Pair(P []bn254.G1Affine, Q []bn254.G2Affine) (bn254.GT, error) {
 
 // PairingCheck replaces bn254.PairingCheck (signature/bls01_signature/bls_signature.go:81).
 func PairingCheck(P []bn254.G1Affine, Q []bn254.G2Affine) (bool, error) {
+	defer pin()()
 	if len(P) == 0 || len(P) != len(Q) {
 		return false, errSizes
 	}
@@ -97,6 +116,7 @@ func PairingCheck(P []bn254.G1Affine, Q []bn254.G2Affine) (bool, error) {
 
 // PairBatch is the batched form the engine adds: out[i] = Pair([P[i]], [Q[i]]).
 func PairBatch(P []bn254.G1Affine, Q []bn254.G2Affine) ([]bn254.GT, error) {
+	defer pin()()
 	if len(P) == 0 || len(P) != len(Q) {
 		return nil, errSizes
 	}
@@ -110,6 +130,7 @@ func PairBatch(P []bn254.G1Affine, Q []bn254.G2Affine) ([]bn254.GT, error) {
 // from single pairings, GT.Mul / Div / Exp (ibe/bb04_ibe/bb04_ibe.go:213-225, access/tree/access_tree_node.go:106-157,
 // bibe/afp25_bibe/afp25_bibe.go:395-413) with one final exponentiation per segment.
 func MultiPair(P []bn254.G1Affine, Q []bn254.G2Affine, segOff []uint64) ([]bn254.GT, error) {
+	defer pin()()
 	if len(segOff) < 2 || len(P) != len(Q) || segOff[len(segOff)-1] != uint64(len(P)) {
 		return nil, errSizes
 	}
@@ -125,6 +146,7 @@ func MultiPair(P []bn254.G1Affine, Q []bn254.G2Affine, segOff []uint64) ([]bn254
 // PairFixedQ: out[j] = Pair(P[j*m:(j+1)*m], Q) for one shared list Q of m points (a BSW07 key against many ciphertexts:
 // access/tree/access_tree_node.go:106-119 under cpabe/bsw07/bsw07_cpabe.go:172-195; gnark: PrecomputeLines).
 func PairFixedQ(P []bn254.G1Affine, Q []bn254.G2Affine) ([]bn254.GT, error) {
+	defer pin()()
 	if len(Q) == 0 || len(P) == 0 || len(P)%len(Q) != 0 {
 		return nil, errSizes
 	}
@@ -147,6 +169,7 @@ func scalarBytes(s *big.Int, dst *[32]byte) {
 // G1ScalarMultiplication replaces new(bn254.G1Affine).ScalarMultiplication(a, s)
 // (signature/bls01_signature/bls_signature.go:45; cpabe/bsw07/bsw07_cpabe.go:69,149,157,160).
 func G1ScalarMultiplication(p, a *bn254.G1Affine, s *big.Int) *bn254.G1Affine {
+	defer pin()()
 	var k [32]byte
 	scalarBytes(s, &k)
 	var out bn254.G1Affine // a and p may alias
@@ -155,15 +178,36 @@ func G1ScalarMultiplication(p, a *bn254.G1Affine, s *big.Int) *bn254.G1Affine {
 	return p
 }
 
-// G1ScalarMultiplicationBase replaces new(bn254.G1Affine).ScalarMultiplicationBase(s).
+// Fixed-base window tables of the two generators (1 MB / 2 MB of HBM), built on the first ScalarMultiplicationBase call:
+// 32 mixed additions per multiplication instead of the variable-base kernel's doublings.
+var (
+	genOnce          sync.Once
+	g1Table, g2Table *C.gpbc_fixed_base
+)
+
+func generatorTables() {
+	genOnce.Do(func() {
+		_, _, g1, g2 := bn254.Generators()
+		must(C.gpbc_g1_fixed_base_create(unsafe.Pointer(&g1), 1, &g1Table))
+		must(C.gpbc_g2_fixed_base_create(unsafe.Pointer(&g2), 1, &g2Table))
+	})
+}
+
+// G1ScalarMultiplicationBase replaces new(bn254.G1Affine).ScalarMultiplicationBase(s)
+// (cpabe/bsw07/bsw07_cpabe.go:69; bibe/afp25_bibe/afp25_bibe.go:160).
 func G1ScalarMultiplicationBase(p *bn254.G1Affine, s *big.Int) *bn254.G1Affine {
-	_, _, g1, _ := bn254.Generators()
-	return G1ScalarMultiplication(p, &g1, s)
+	defer pin()()
+	generatorTables()
+	var k [32]byte
+	scalarBytes(s, &k)
+	must(C.gpbc_fixed_base_msm(g1Table, unsafe.Pointer(&k[0]), 1, unsafe.Pointer(p)))
+	return p
 }
 
 // G2ScalarMultiplication replaces new(bn254.G2Affine).ScalarMultiplication(a, s)
 // (signature/bls01_signature/bls_signature.go:63; cpabe/bsw07/bsw07_cpabe.go:73,83,103-121).
 func G2ScalarMultiplication(p, a *bn254.G2Affine, s *big.Int) *bn254.G2Affine {
+	defer pin()()
 	var k [32]byte
 	scalarBytes(s, &k)
 	var out bn254.G2Affine
@@ -172,10 +216,15 @@ func G2ScalarMultiplication(p, a *bn254.G2Affine, s *big.Int) *bn254.G2Affine {
 	return p
 }
 
-// G2ScalarMultiplicationBase replaces new(bn254.G2Affine).ScalarMultiplicationBase(s).
+// G2ScalarMultiplicationBase replaces new(bn254.G2Affine).ScalarMultiplicationBase(s)
+// (cpabe/bsw07/bsw07_cpabe.go:73; bibe/afp25_bibe/afp25_bibe.go:164-165).
 func G2ScalarMultiplicationBase(p *bn254.G2Affine, s *big.Int) *bn254.G2Affine {
-	_, _, _, g2 := bn254.Generators()
-	return G2ScalarMultiplication(p, &g2, s)
+	defer pin()()
+	generatorTables()
+	var k [32]byte
+	scalarBytes(s, &k)
+	must(C.gpbc_fixed_base_msm(g2Table, unsafe.Pointer(&k[0]), 1, unsafe.Pointer(p)))
+	return p
 }
 
 func frBytes(s []fr.Element) [][32]byte {
@@ -189,6 +238,7 @@ func frBytes(s []fr.Element) [][32]byte {
 
 // G1ScalarMultiplicationBatch: out[i] = [s[i]] bases[i]  (len(bases) == 1 shares the base, e.g. ScalarMultiplicationBase).
 func G1ScalarMultiplicationBatch(bases []bn254.G1Affine, s []fr.Element) ([]bn254.G1Affine, error) {
+	defer pin()()
 	if len(s) == 0 {
 		return nil, nil
 	}
@@ -204,6 +254,7 @@ func G1ScalarMultiplicationBatch(bases []bn254.G1Affine, s []fr.Element) ([]bn25
 
 // G2ScalarMultiplicationBatch: the same over G2.
 func G2ScalarMultiplicationBatch(bases []bn254.G2Affine, s []fr.Element) ([]bn254.G2Affine, error) {
+	defer pin()()
 	if len(s) == 0 {
 		return nil, nil
 	}
@@ -221,6 +272,7 @@ func G2ScalarMultiplicationBatch(bases []bn254.G2Affine, s []fr.Element) ([]bn25
 // combination (a loop of ScalarMultiplication + Add in the reference's style, gka/agka09/asbb.go:193-220), sharded over
 // all bound GPUs with the partial sums combined inside the library.
 func G1ScalarMulSum(bases []bn254.G1Affine, s []fr.Element) (bn254.G1Affine, error) {
+	defer pin()()
 	var out bn254.G1Affine
 	if len(bases) != len(s) {
 		return out, errSizes
@@ -235,6 +287,7 @@ func G1ScalarMulSum(bases []bn254.G1Affine, s []fr.Element) (bn254.G1Affine, err
 
 // G2ScalarMulSum: the same over G2.
 func G2ScalarMulSum(bases []bn254.G2Affine, s []fr.Element) (bn254.G2Affine, error) {
+	defer pin()()
 	var out bn254.G2Affine
 	if len(bases) != len(s) {
 		return out, errSizes
@@ -259,6 +312,7 @@ func gtExp256(x *bn254.GT, e *[32]byte) bn254.GT {
 // SetRandom messages do not): a negative k inverts x first; an exponent wider than the kernel's 256 bits is evaluated in
 // 256-bit digits, x^k = prod_i (x^(2^(256 i)))^(k_i).  The reference's call sites pass values below r: one digit.
 func GTExp(z *bn254.GT, x bn254.GT, k *big.Int) *bn254.GT {
+	defer pin()()
 	var abs big.Int
 	abs.Abs(k)
 	base := x
@@ -298,9 +352,33 @@ func GTExp(z *bn254.GT, x bn254.GT, k *big.Int) *bn254.GT {
 	return z
 }
 
-// GTMul / GTDiv / GTInverse replace (*GT).Mul / Div / Inverse (access/tree/access_tree_node.go:114,157;
-// cpabe/bsw07/bsw07_cpabe.go:189-190).  Batched: one element per index.
+// GTMul, GTDiv, GTInverse replace new(bn254.GT).Mul(x, y) / Div(x, y) / Inverse(x) with gnark's signatures
+// (access/tree/access_tree_node.go:114,157; cpabe/bsw07/bsw07_cpabe.go:189-190): z may alias an operand.
+func GTMul(z, x, y *bn254.GT) *bn254.GT {
+	defer pin()()
+	var out bn254.GT
+	must(C.gpbc_gt_mul_batch(unsafe.Pointer(x), unsafe.Pointer(y), 1, unsafe.Pointer(&out)))
+	*z = out
+	return z
+}
+func GTDiv(z, x, y *bn254.GT) *bn254.GT {
+	defer pin()()
+	var out bn254.GT
+	must(C.gpbc_gt_div_batch(unsafe.Pointer(x), unsafe.Pointer(y), 1, unsafe.Pointer(&out)))
+	*z = out
+	return z
+}
+func GTInverse(z, x *bn254.GT) *bn254.GT {
+	defer pin()()
+	var out bn254.GT
+	must(C.gpbc_gt_inverse_batch(unsafe.Pointer(x), 1, unsafe.Pointer(&out)))
+	*z = out
+	return z
+}
+
+// The batched forms: one element per index.
 func GTMulBatch(a, b []bn254.GT) ([]bn254.GT, error) {
+	defer pin()()
 	if len(a) != len(b) {
 		return nil, errSizes
 	}
@@ -312,6 +390,7 @@ func GTMulBatch(a, b []bn254.GT) ([]bn254.GT, error) {
 	return out, status(rc)
 }
 func GTDivBatch(a, b []bn254.GT) ([]bn254.GT, error) {
+	defer pin()()
 	if len(a) != len(b) {
 		return nil, errSizes
 	}
@@ -327,6 +406,7 @@ func GTDivBatch(a, b []bn254.GT) ([]bn254.GT, error) {
 // (serialization/serialization_curve.go:5-7,17-21) n elements per call.  Unlike the reference, the decode error is
 // returned per element, not dropped.
 func MarshalG1Batch(pts []bn254.G1Affine, compressed bool) []byte {
+	defer pin()()
 	w, c := 64, C.int(0)
 	if compressed {
 		w, c = 32, 1
@@ -338,6 +418,7 @@ func MarshalG1Batch(pts []bn254.G1Affine, compressed bool) []byte {
 	return out
 }
 func UnmarshalG1Batch(data []byte, elemBytes int) ([]bn254.G1Affine, []bool, error) {
+	defer pin()()
 	if elemBytes != 32 && elemBytes != 64 {
 		return nil, nil, errors.New("G1 element size must be 32 or 64")
 	}
@@ -354,6 +435,7 @@ func UnmarshalG1Batch(data []byte, elemBytes int) ([]bn254.G1Affine, []bool, err
 	return out, ok, status(rc)
 }
 func MarshalG2Batch(pts []bn254.G2Affine, compressed bool) []byte {
+	defer pin()()
 	w, c := 128, C.int(0)
 	if compressed {
 		w, c = 64, 1
@@ -365,6 +447,7 @@ func MarshalG2Batch(pts []bn254.G2Affine, compressed bool) []byte {
 	return out
 }
 func UnmarshalG2Batch(data []byte, elemBytes int) ([]bn254.G2Affine, []bool, error) {
+	defer pin()()
 	if elemBytes != 64 && elemBytes != 128 {
 		return nil, nil, errors.New("G2 element size must be 64 or 128")
 	}
@@ -381,6 +464,7 @@ func UnmarshalG2Batch(data []byte, elemBytes int) ([]bn254.G2Affine, []bool, err
 	return out, ok, status(rc)
 }
 func MarshalGTBatch(gt []bn254.GT) []byte { // GT.Marshal() = GT.Bytes() (hash/hash_from_gt.go:5-8)
+	defer pin()()
 	out := make([]byte, 384*len(gt))
 	if len(gt) > 0 {
 		must(C.gpbc_gt_marshal_batch(unsafe.Pointer(unsafe.SliceData(gt)), C.size_t(len(gt)), unsafe.Pointer(unsafe.SliceData(out))))
@@ -388,9 +472,89 @@ func MarshalGTBatch(gt []bn254.GT) []byte { // GT.Marshal() = GT.Bytes() (hash/h
 	return out
 }
 
+// UnmarshalG1, UnmarshalG2, UnmarshalGT replace (*G1Affine).Unmarshal(buf) / (*G2Affine).Unmarshal / (*GT).Unmarshal
+// (serialization/serialization_curve.go:17-33, whose callers drop the error).  Like gnark they accept the compressed and the
+// uncompressed form by the flag bits of the first byte and return an error for a short buffer, a coordinate >= p, a point off
+// the curve or outside the subgroup; the receiver is then left zero.
+var errShort = errors.New("short buffer")
+var errInvalidEncoding = errors.New("invalid point encoding")
+
+func UnmarshalG1(p *bn254.G1Affine, buf []byte) error {
+	defer pin()()
+	if len(buf) < 32 {
+		return errShort
+	}
+	size := 64
+	if buf[0]&0xC0 != 0 { // mCompressedSmallest, mCompressedLargest or mCompressedInfinity
+		size = 32
+	} else if len(buf) < 64 {
+		return errShort
+	}
+	var ok C.uint8_t
+	if err := status(C.gpbc_g1_unmarshal_batch(unsafe.Pointer(unsafe.SliceData(buf)), C.size_t(size), 1, unsafe.Pointer(p), &ok)); err != nil {
+		return err
+	}
+	if ok != 1 {
+		return errInvalidEncoding
+	}
+	return nil
+}
+func UnmarshalG2(p *bn254.G2Affine, buf []byte) error {
+	defer pin()()
+	if len(buf) < 64 {
+		return errShort
+	}
+	size := 128
+	if buf[0]&0xC0 != 0 {
+		size = 64
+	} else if len(buf) < 128 {
+		return errShort
+	}
+	var ok C.uint8_t
+	if err := status(C.gpbc_g2_unmarshal_batch(unsafe.Pointer(unsafe.SliceData(buf)), C.size_t(size), 1, unsafe.Pointer(p), &ok)); err != nil {
+		return err
+	}
+	if ok != 1 {
+		return errInvalidEncoding
+	}
+	return nil
+}
+func UnmarshalGT(z *bn254.GT, buf []byte) error {
+	defer pin()()
+	if len(buf) < 384 {
+		return errShort
+	}
+	var ok C.uint8_t
+	if err := status(C.gpbc_gt_unmarshal_batch(unsafe.Pointer(unsafe.SliceData(buf)), 1, unsafe.Pointer(z), &ok)); err != nil {
+		return err
+	}
+	if ok != 1 {
+		return errInvalidEncoding
+	}
+	return nil
+}
+
+// HashToG1 and HashToG2 replace bn254.HashToG1(msg, dst) / bn254.HashToG2(msg, dst) with gnark's signatures
+// (hash/hash_to.go:114,170,205,272 — one call per string in the reference).
+func HashToG1(msg, dst []byte) (bn254.G1Affine, error) {
+	out, err := HashToG1Batch([][]byte{msg}, dst)
+	if err != nil {
+		return bn254.G1Affine{}, err
+	}
+	return out[0], nil
+}
+func HashToG2(msg, dst []byte) (bn254.G2Affine, error) {
+	out, err := HashToG2Batch([][]byte{msg}, dst)
+	if err != nil {
+		return bn254.G2Affine{}, err
+	}
+	return out[0], nil
+}
+
 // HashToG1Batch replaces bn254.HashToG1(msg, dst) (hash/hash_to.go:113-119,169-175) for a batch: the engine hashes
 // (expand_message_xmd with SHA-256, reduction to two field elements), maps both, adds.
 func HashToG1Batch(msgs [][]byte, dst []byte) ([]bn254.G1Affine, error) {
+	defer pin()()
 	out := make([]bn254.G1Affine, len(msgs))
 	if len(msgs) == 0 {
 		return out, nil
@@ -400,13 +564,14 @@ func HashToG1Batch(msgs [][]byte, dst []byte) ([]bn254.G1Affine, error) {
 	}
 	data, off := flatten(msgs)
 	rc := C.gpbc_hash_to_g1(unsafe.Pointer(unsafe.SliceData(data)), (*C.uint64_t)(unsafe.SliceData(off)), C.size_t(len(msgs)),
-		unsafe.Pointer(unsafe.SliceData(dst)), C.size_t(len(dst)), unsafe.Pointer(unsafe.SliceData(out)))
+		dstPointer(dst), C.size_t(len(dst)), unsafe.Pointer(unsafe.SliceData(out)))
 	return out, status(rc)
 }
 
 // MapToG1Batch is the group part alone for callers that hold gnark's fp.Hash(msg, dst, 2) output already: u has two
 // elements per point, out[i] = MapToCurve1(u[2i]) + MapToCurve1(u[2i+1]).
 func MapToG1Batch(u []fp.Element) ([]bn254.G1Affine, error) {
+	defer pin()()
 	if len(u)%2 != 0 {
 		return nil, errors.New("two field elements per point")
 	}
@@ -421,6 +586,7 @@ func MapToG1Batch(u []fp.Element) ([]bn254.G1Affine, error) {
 // HashToG2Batch replaces bn254.HashToG2 (hash/hash_to.go:204-210,271-277): four base-field elements per message,
 // E2 j = elements 2j (A0) and 2j+1 (A1); hashing, both maps, addition and cofactor clearing in one call.
 func HashToG2Batch(msgs [][]byte, dst []byte) ([]bn254.G2Affine, error) {
+	defer pin()()
 	out := make([]bn254.G2Affine, len(msgs))
 	if len(msgs) == 0 {
 		return out, nil
@@ -430,8 +596,17 @@ func HashToG2Batch(msgs [][]byte, dst []byte) ([]bn254.G2Affine, error) {
 	}
 	data, off := flatten(msgs)
 	rc := C.gpbc_hash_to_g2(unsafe.Pointer(unsafe.SliceData(data)), (*C.uint64_t)(unsafe.SliceData(off)), C.size_t(len(msgs)),
-		unsafe.Pointer(unsafe.SliceData(dst)), C.size_t(len(dst)), unsafe.Pointer(unsafe.SliceData(out)))
+		dstPointer(dst), C.size_t(len(dst)), unsafe.Pointer(unsafe.SliceData(out)))
 	return out, status(rc)
+}
+
+// dstPointer: an empty domain-separation tag is legal (the library accepts dst == NULL with dst_len == 0, and so does this shim:
+// unsafe.SliceData of an empty slice may be nil).
+func dstPointer(dst []byte) unsafe.Pointer {
+	if len(dst) == 0 {
+		return nil
+	}
+	return unsafe.Pointer(unsafe.SliceData(dst))
 }
 
 // flatten lays the messages back to back with their n+1 byte offsets (the layout of gpbc_hash_to_*).

@@ -45,7 +45,9 @@ typedef enum {
     GPBC_ERR_NO_DEVICE = -2,     /* no HIP device / gpbc_init not successful */
     GPBC_ERR_HIP = -3,           /* a HIP runtime call failed; see gpbc_last_error() */
     GPBC_ERR_WORKSPACE = -4,     /* *_dev call given a workspace smaller than gpbc_*_workspace_bytes() */
-    GPBC_ERR_COMM = -5           /* RCCL missing or a collective failed; see gpbc_last_error() */
+    GPBC_ERR_COMM = -5,          /* RCCL missing or a collective failed; see gpbc_last_error() */
+    GPBC_ERR_INTERNAL = -6       /* a self-check of the library failed (e.g. the multi-pairing kernels did not consume exactly the pairs of
+                                    the caller's segment table); outputs are zeroed, nothing computed by the call may be used */
 } gpbc_status;
 
 /* ---- lifetime and devices ----------------------------------------------------------------------
@@ -137,6 +139,12 @@ int gpbc_set_multi_pair_chunk(int pairs_per_chunk);
  * large batches (tests compare the two); default 1.  2 = pipelined with no waiting at all (a consumer that finds its line
  * missing computes its own lines: the bounded-wait fallback, for tests). */
 int gpbc_set_pipelined_miller(int on);
+/* Fail-closed self-check of the host-table multi-pairings (gpbc_multi_pair, gpbc_pairing_check, gpbc_multi_pair_hostseg_dev): the
+ * segment / chunk tables travel through library-owned pinned memory, the kernels echo the pairs they consumed per segment, and
+ * the call returns GPBC_ERR_INTERNAL with zeroed outputs unless the echo equals the caller's table — a product over fewer pairs
+ * than were passed (an empty product is GT one, i.e. "PairingCheck = true") can never come back as a result.  Test knob: the next
+ * such call sends the device a table whose last segment is empty (what a stale table looks like) and must fail. */
+int gpbc_debug_stale_table_once(void);
 
 /* bn254.PairingCheck(P, Q) (bool, error), k times (signature/bls01_signature/bls_signature.go:81):
  * ok_out[j] = 1 iff the product over segment j is GT one. */
@@ -172,9 +180,9 @@ int gpbc_g2_sum_dev(const void *d_pts, size_t n, void *d_out, void *d_workspace,
 /* sum_i [s_i] P_i — the verifier's side of BLS aggregate verification with random linear combination (BASELINE config 3:
  * A = sum rho_i pk_i in G1, B = sum rho_i sigma_i in G2; signature/bls01_signature/bls_signature.go:71-89 verifies one,
  * gka/agka09/asbb_test.go:203-238 has the aggregate shape).  nbase == n.
- * Host form: sharded over the bound devices like every batch entry; each device reduces its shard to one partial sum, and
- * the partial sums are combined on device 0 — exchanged by ONE RCCL all-gather of a point per rank when
- * gpbc_comm_init_all() was called, through the host otherwise.
+ * Host form: sharded over the bound devices like every batch entry; each device reduces its shard to one partial sum, the
+ * partial sums come back to the host (one point per device) and the calling thread's device adds them — no collective: the
+ * data of a host-pointer call is on the host anyway.
  * _dev form (one process per GPU): the calling rank's shard in device memory; with a communicator (gpbc_comm_init_rank)
  * the partial sums of all ranks are all-gathered and added, so every rank ends with the global sum; without one the
  * result is the local sum.  Stream-ordered, not synchronised. */
@@ -277,6 +285,12 @@ int gpbc_hash_to_field_dev(const void *d_msgs, const uint64_t *d_msg_off, size_t
  * in ms and the number of launches.  One measurement at a time per process. */
 int gpbc_profile_begin(void *stream);
 int gpbc_profile_end(char *names_out, double *total_ms_out, int *launches_out, int max_kernels, int *n_kernels_out);
+/* The roofline's denominator measured NOW on the current device ("measured peak v_mad_u64_u32 rate ... from a
+ * dependency-free micro-benchmark kernel run on the box"): a ~2 ms kernel of independent v_mad_u64_u32 chains at 8 waves per
+ * SIMD.  out[0] = MACs per second (lane operations), out[1] = shader clock in Hz while it ran (s_memtime against the 100 MHz
+ * s_memrealtime), out[2] = SIMD cycles per wave-instruction at that clock, out[3] = kernel duration in ms.  Synchronises the
+ * device's null stream.  bench.py reports roofline.frac against this same-run figure beside the fixed 34.9 T/s of round 1. */
+int gpbc_valu_probe(double *out4);
 
 /* ---- field-level entry (kernel unit tests) ------------------------------------------------------ */
 int gpbc_fp_mul_batch(const void *a, const void *b, size_t n, void *out);

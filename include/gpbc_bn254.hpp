@@ -133,8 +133,21 @@ inline void Generators(G1Affine &g1, G2Affine &g2) {
     g2.Y.A1 = {{0x64095b56c71856eeULL, 0xdc57f922327d3cbbULL, 0x55f935be33351076ULL, 0x0da4a0e693fd6482ULL}};
 }
 inline G1Affine &G1Affine::Neg(const G1Affine &a) { X = a.X; Y = fpNeg(a.Y); return *this; }
-inline G1Affine &G1Affine::ScalarMultiplicationBase(const Scalar &s) { G1Affine g1; G2Affine g2; Generators(g1, g2); return ScalarMultiplication(g1, s); }
-inline G2Affine &G2Affine::ScalarMultiplicationBase(const Scalar &s) { G1Affine g1; G2Affine g2; Generators(g1, g2); return ScalarMultiplication(g2, s); }
+// ScalarMultiplicationBase: fixed-base window tables of the two generators (1 MB / 2 MB of HBM), built on the first call and
+// kept for the life of the process — 32 mixed additions per multiplication instead of the variable-base kernel's doublings.
+namespace detail {
+struct GeneratorTables {
+    gpbc_fixed_base *g1 = nullptr, *g2 = nullptr;
+    GeneratorTables() {
+        G1Affine a; G2Affine b; Generators(a, b);
+        check(gpbc_g1_fixed_base_create(&a, 1, &g1));
+        check(gpbc_g2_fixed_base_create(&b, 1, &g2));
+    }
+};
+inline const GeneratorTables &generator_tables() { static const GeneratorTables t; return t; }   // C++11: initialised once, thread-safe
+}  // namespace detail
+inline G1Affine &G1Affine::ScalarMultiplicationBase(const Scalar &s) { check(gpbc_fixed_base_msm(detail::generator_tables().g1, s.le.data(), 1, this)); return *this; }
+inline G2Affine &G2Affine::ScalarMultiplicationBase(const Scalar &s) { check(gpbc_fixed_base_msm(detail::generator_tables().g2, s.le.data(), 1, this)); return *this; }
 
 // bn254.Pair: product of pairings, one final exponentiation.  gnark's error: "invalid inputs sizes".
 inline GT Pair(const std::vector<G1Affine> &P, const std::vector<G2Affine> &Q) {

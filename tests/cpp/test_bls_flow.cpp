@@ -3,6 +3,7 @@
 // plus the wrong-message / wrong-key negatives.  The message point is the real hash, bn254.HashToG2(msg, dst) with the
 // reference's DST (hash/hash_to.go:204-210), computed on the device; bls_signature.go:58-89.
 #include <cstdio>
+#include <cstring>
 #include <string>
 #include "gpbc_bn254.hpp"
 
@@ -89,6 +90,44 @@ int main() {
         t5.ScalarMultiplication(g1, Scalar(5)); t7.ScalarMultiplication(a.pk, Scalar(7));
         check(gpbc_g1_sum(std::vector<G1Affine>{t5, t7}.data(), 2, &want));
         EXPECT(s.size() == 2 && s[0].Equal(want) && s[1].Equal(a.pk));
+    }
+    // forged-signature reject through every host-table multi-pairing path (general = one Miller loop per pair, pipelined or two
+    // kernels; shared-squaring chunks), repeated so that every call finds the previous call's tables in the recycled scratch and
+    // pinned staging buffers; then the fail-closed self-check: a device table that is not the caller's must fail the call
+    // (profiles/r02_pool_bisect.txt is the failure this guards against: "true" for a forged signature from an empty product)
+    {
+        G2Affine hm = HashStandIn("hello pairing"), inv, forged_inv; inv.Neg(sig);
+        G2Affine forged = Sign(b.sk, "hello pairing"); forged_inv.Neg(forged);       // b's signature offered under a's key
+        struct Mode { const char *name; int chunk, pipelined; };
+        const Mode modes[] = {{"general", 0, 1}, {"two-kernel Miller loop", 0, 0}, {"pipelined without waiting", 0, 2}, {"chunks of 2", 2, 1}, {"chunks of 1", 1, 1}};
+        for (const Mode &m : modes) {
+            check(gpbc_set_multi_pair_chunk(m.chunk)); check(gpbc_set_pipelined_miller(m.pipelined));
+            for (int rep = 0; rep < 3; rep++) {
+                EXPECT(Verify(a.pk, "hello pairing", sig));
+                EXPECT(!PairingCheck({a.pk, g1}, {hm, forged_inv}));
+                // valid, forged and empty segment in one call (an empty product IS one); then the same pairs in the other order
+                const G1Affine Ps[4] = {a.pk, g1, a.pk, g1};
+                const G2Affine Qv[4] = {hm, inv, hm, forged_inv}, Qw[4] = {hm, forged_inv, hm, inv};
+                const uint64_t seg[4] = {0, 2, 4, 4};
+                uint8_t ok[3] = {9, 9, 9};
+                check(gpbc_pairing_check(Ps, Qv, seg, 3, ok));
+                EXPECT(ok[0] == 1 && ok[1] == 0 && ok[2] == 1);
+                check(gpbc_pairing_check(Ps, Qw, seg, 3, ok));
+                EXPECT(ok[0] == 0 && ok[1] == 1 && ok[2] == 1);
+            }
+            const G1Affine Ps[2] = {a.pk, g1};
+            const G2Affine Qf[2] = {hm, forged_inv};
+            const uint64_t seg[2] = {0, 2};
+            uint8_t ok[1] = {9};
+            GT out;
+            check(gpbc_debug_stale_table_once());
+            EXPECT(gpbc_pairing_check(Ps, Qf, seg, 1, ok) == GPBC_ERR_INTERNAL && ok[0] != 1);      // the device saw an empty segment: refused, not "true"
+            check(gpbc_debug_stale_table_once());
+            EXPECT(gpbc_multi_pair(Ps, Qf, seg, 1, &out) == GPBC_ERR_INTERNAL);
+            EXPECT(!PairingCheck({a.pk, g1}, {hm, forged_inv}) && Verify(a.pk, "hello pairing", sig));   // and the next calls are sound
+            printf("  multi-pairing path '%s': accepts, rejects, fails closed on a stale table\n", m.name);
+        }
+        check(gpbc_set_multi_pair_chunk(0)); check(gpbc_set_pipelined_miller(1));
     }
     printf("BLS flow OK\n");
     return 0;

@@ -11,6 +11,7 @@
 //        -L gopairingbasedcryptography_amd -lgpbc_bn254 -L /opt/rocm/lib -lamdhip64
 #include <hip/hip_runtime_api.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <string>
@@ -188,17 +189,22 @@ int main() {
         printf("one thread per device slot with *_dev entries: OK\n");
     }
 
-    // ---- 3. RCCL all-gather inside the library (distinct devices only: RCCL refuses a GPU listed twice)
-    if (shared_gpu) Init(std::vector<int>{0});
+    // ---- 3. RCCL all-gather inside the library.  Real RCCL refuses a GPU listed twice, so on a one-GPU box the list shrinks to {0}
+    // (one rank) — unless GPBC_TEST_STUB_RCCL is set and tests/stub_rccl/librccl.so.1 (a host-rendezvous + device-copy test double)
+    // is on the library path: then the {0, 0} list stays and everything below runs with TWO ranks.
+    const bool stub = getenv("GPBC_TEST_STUB_RCCL") != nullptr;
+    if (shared_gpu && !stub) Init(std::vector<int>{0});
     const int nr = NumDevices();
     if (gpbc_comm_init_all() < 0) { printf("FAIL: gpbc_comm_init_all: %s\n", gpbc_last_error()); return 1; }
     EXPECT(gpbc_comm_ranks() == nr);
+    if (stub) EXPECT(nr >= 2);
     {
-        const size_t rows = 1024, bytes = rows * 384;                    // GT rows per rank (BASELINE config 5 shape)
+        const size_t rows = 1024, bytes = rows * 384;                    // GT rows per rank (BASELINE config 5 shape: the AFP25 masks)
         std::vector<void *> send(nr), recv(nr);
         for (int d = 0; d < nr; d++) {
             HIP_OK(hipSetDevice(gpbc_device_at(d)));
             HIP_OK(hipMalloc(&send[d], bytes)); HIP_OK(hipMalloc(&recv[d], bytes * nr));
+            HIP_OK(hipMemset(recv[d], 0xEE, bytes * nr));
             HIP_OK(hipMemcpy(send[d], &E[d * rows], bytes, hipMemcpyHostToDevice));
         }
         check(gpbc_allgather_all_dev(send.data(), bytes, recv.data(), nullptr));
@@ -207,30 +213,85 @@ int main() {
             HIP_OK(hipSetDevice(gpbc_device_at(d)));
             HIP_OK(hipDeviceSynchronize());
             HIP_OK(hipMemcpy(got.data(), recv[d], bytes * nr, hipMemcpyDeviceToHost));
-            EXPECT(std::memcmp(got.data(), E.data(), bytes * nr) == 0);
+            EXPECT(std::memcmp(got.data(), E.data(), bytes * nr) == 0);      // rank order and offsets: rank q's rows at q * bytes, on every rank
             hipFree(send[d]); hipFree(recv[d]);
         }
-        // the aggregate-verify sums again, now with the partial sums exchanged by RCCL
+        // the aggregate-verify sums through the host entry (sharded over the slots, partial sums combined on the host)
         G1Affine Ar; G2Affine Br;
         check(gpbc_g1_scalar_mul_sum(P.data(), c.data(), N, &Ar));
         check(gpbc_g2_scalar_mul_sum(Q.data(), c.data(), N, &Br));
         EXPECT(Ar.Equal(A) && Br.Equal(B));
-        // _dev form on rank 0's device: with a one-rank communicator the global sum is the local one
-        if (nr == 1) {
-            void *dB, *dS, *dO;
-            HIP_OK(hipMalloc(&dB, N * 64)); HIP_OK(hipMalloc(&dS, N * 32)); HIP_OK(hipMalloc(&dO, 64));
-            HIP_OK(hipMemcpy(dB, P.data(), N * 64, hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(dS, c.data(), N * 32, hipMemcpyHostToDevice));
-            check(gpbc_g1_scalar_mul_sum_dev(dB, dS, N, dO, nullptr));
-            G1Affine Ad;
-            HIP_OK(hipDeviceSynchronize());
-            HIP_OK(hipMemcpy(&Ad, dO, 64, hipMemcpyDeviceToHost));
-            EXPECT(Ad.Equal(A));
-            hipFree(dB); hipFree(dS); hipFree(dO);
+        // ... and through the device-resident composite, one host thread per rank with its own shard and stream: local bucket
+        // sum, all-gather of one point per rank INSIDE the library (per-thread ncclAllGather on the rank's communicator), sum of the
+        // gathered partials — every rank must end with the global sum
+        {
+            std::vector<std::thread> th;
+            std::vector<int> bad(nr, 0);
+            std::vector<G1Affine> A_rank(nr);
+            std::vector<G2Affine> B_rank(nr);
+            for (int d = 0; d < nr; d++)
+                th.emplace_back([&, d]() {
+                    auto fail_here = [&](int line) { bad[d] = line; };
+                    if (gpbc_set_device(d) < 0 || hipSetDevice(gpbc_device_at(d)) != hipSuccess) return fail_here(__LINE__);
+                    const size_t lo = N * d / nr, hi = N * (d + 1) / nr, m = hi - lo;
+                    hipStream_t st;
+                    if (hipStreamCreate(&st) != hipSuccess) return fail_here(__LINE__);
+                    void *dB1, *dB2, *dS, *dO1, *dO2;
+                    if (hipMalloc(&dB1, m * 64) != hipSuccess || hipMalloc(&dB2, m * 128) != hipSuccess || hipMalloc(&dS, m * 32) != hipSuccess ||
+                        hipMalloc(&dO1, 64) != hipSuccess || hipMalloc(&dO2, 128) != hipSuccess) return fail_here(__LINE__);
+                    hipMemcpyAsync(dB1, &P[lo], m * 64, hipMemcpyHostToDevice, st);
+                    hipMemcpyAsync(dB2, &Q[lo], m * 128, hipMemcpyHostToDevice, st);
+                    hipMemcpyAsync(dS, &c[lo], m * 32, hipMemcpyHostToDevice, st);
+                    if (gpbc_g1_scalar_mul_sum_dev(dB1, dS, m, dO1, st) < 0) return fail_here(__LINE__);
+                    if (gpbc_g2_scalar_mul_sum_dev(dB2, dS, m, dO2, st) < 0) return fail_here(__LINE__);
+                    hipMemcpyAsync(&A_rank[d], dO1, 64, hipMemcpyDeviceToHost, st);
+                    hipMemcpyAsync(&B_rank[d], dO2, 128, hipMemcpyDeviceToHost, st);
+                    if (hipStreamSynchronize(st) != hipSuccess) return fail_here(__LINE__);
+                    hipFree(dB1); hipFree(dB2); hipFree(dS); hipFree(dO1); hipFree(dO2); hipStreamDestroy(st);
+                });
+            for (auto &t : th) t.join();
+            for (int d = 0; d < nr; d++) { if (bad[d]) printf("rank %d failed at line %d: %s\n", d, bad[d], gpbc_last_error()); EXPECT(bad[d] == 0); }
+            for (int d = 0; d < nr; d++) EXPECT(A_rank[d].Equal(A) && B_rank[d].Equal(B));
+            printf("scalar_mul_sum_dev on %d rank(s), partial sums all-gathered inside the library: every rank holds the global sums\n", nr);
+        }
+        // BLS aggregate verification with the verifier's sums taken from the collective path: accepts, and rejects a forged signature
+        {
+            const size_t n = 10000;
+            G2Affine H; H.ScalarMultiplicationBase(Scalar(0xABCDEF12345ull));
+            std::vector<Scalar> x(a.begin() + 100, a.begin() + 100 + n), rho(c.begin(), c.begin() + n);
+            for (auto &r : rho) for (int j = 16; j < 32; j++) r.le[j] = 0;
+            std::vector<G1Affine> pk = G1ScalarMultiplicationBatch({g1}, x);
+            std::vector<G2Affine> sg = G2ScalarMultiplicationBatch({H}, x);
+            for (int forged = 0; forged < 2; forged++) {
+                if (forged) sg[n / 3] = sg[n / 3 + 1];
+                std::vector<G1Affine> Ag(nr); std::vector<G2Affine> Bg(nr);
+                std::vector<std::thread> th; std::vector<int> bad(nr, 0);
+                for (int d = 0; d < nr; d++)
+                    th.emplace_back([&, d]() {
+                        if (gpbc_set_device(d) < 0 || hipSetDevice(gpbc_device_at(d)) != hipSuccess) { bad[d] = __LINE__; return; }
+                        const size_t lo = n * d / nr, hi = n * (d + 1) / nr, m = hi - lo;
+                        void *dB1, *dB2, *dS, *dO1, *dO2;
+                        if (hipMalloc(&dB1, m * 64) != hipSuccess || hipMalloc(&dB2, m * 128) != hipSuccess || hipMalloc(&dS, m * 32) != hipSuccess ||
+                            hipMalloc(&dO1, 64) != hipSuccess || hipMalloc(&dO2, 128) != hipSuccess) { bad[d] = __LINE__; return; }
+                        hipMemcpy(dB1, &pk[lo], m * 64, hipMemcpyHostToDevice); hipMemcpy(dB2, &sg[lo], m * 128, hipMemcpyHostToDevice); hipMemcpy(dS, &rho[lo], m * 32, hipMemcpyHostToDevice);
+                        if (gpbc_g1_scalar_mul_sum_dev(dB1, dS, m, dO1, nullptr) < 0 || gpbc_g2_scalar_mul_sum_dev(dB2, dS, m, dO2, nullptr) < 0) { bad[d] = __LINE__; return; }
+                        if (hipDeviceSynchronize() != hipSuccess) { bad[d] = __LINE__; return; }
+                        hipMemcpy(&Ag[d], dO1, 64, hipMemcpyDeviceToHost); hipMemcpy(&Bg[d], dO2, 128, hipMemcpyDeviceToHost);
+                        hipFree(dB1); hipFree(dB2); hipFree(dS); hipFree(dO1); hipFree(dO2);
+                    });
+                for (auto &t : th) t.join();
+                for (int d = 0; d < nr; d++) { if (bad[d]) printf("rank %d failed at line %d: %s\n", d, bad[d], gpbc_last_error()); EXPECT(bad[d] == 0); }
+                for (int d = 0; d < nr; d++) {                            // every rank can run the 2-pairing check on its own copy of the sums
+                    G2Affine nB; nB.Neg(Bg[d]);
+                    EXPECT(PairingCheck({Ag[d], g1}, {H, nB}) == (forged == 0));
+                }
+            }
+            printf("BLS aggregate verify over %d rank(s) with all-gathered partial sums: accepts, rejects a forged signature\n", nr);
         }
     }
     check(gpbc_comm_destroy());
     EXPECT(gpbc_comm_ranks() == 0);
-    printf("RCCL all-gather over %d rank(s) inside the library: OK\n", nr);
+    printf("RCCL all-gather over %d rank(s) inside the library%s: OK\n", nr, stub ? " (rccl TEST DOUBLE: tests/stub_rccl)" : "");
 
     // BLS aggregate verification (BASELINE config 3) through the boundary: x_i secret keys, pk_i = [x_i]g1, sigma_i = [x_i]H,
     // check e(sum rho_i pk_i, H) * e(g1, -sum rho_i sigma_i) == 1, then forge one signature.
@@ -246,11 +307,45 @@ int main() {
         check(gpbc_g2_scalar_mul_sum(sig.data(), rho.data(), n, &Bg));
         nB.Neg(Bg);
         EXPECT(PairingCheck({Ag, g1}, {H, nB}));
+        const G2Affine sig0_mid = sig[n / 2];
         sig[n / 2] = sig[n / 2 + 1];
         check(gpbc_g2_scalar_mul_sum(sig.data(), rho.data(), n, &Bg));
         nB.Neg(Bg);
         EXPECT(!PairingCheck({Ag, g1}, {H, nB}));
         printf("BLS aggregate verify of %zu signatures: accepts, rejects a forged one\n", n);
+        // the same two checks as ONE call with the points in device memory, the table on the host and a created stream
+        // (gpbc_multi_pair_hostseg_dev), then the fail-closed self-check on that entry: a stale device table fails the call and
+        // leaves zeroed outputs
+        {
+            G2Affine Bok, nBok;
+            sig[n / 2] = sig0_mid;
+            check(gpbc_g2_scalar_mul_sum(sig.data(), rho.data(), n, &Bok));
+            nBok.Neg(Bok);
+            const G1Affine Ps[4] = {Ag, g1, Ag, g1};
+            const G2Affine Qs[4] = {H, nBok, H, nB};
+            const uint64_t seg[3] = {0, 2, 4};
+            hipStream_t st; HIP_OK(hipStreamCreate(&st));
+            void *dP, *dQ, *dG;
+            HIP_OK(hipMalloc(&dP, sizeof Ps)); HIP_OK(hipMalloc(&dQ, sizeof Qs)); HIP_OK(hipMalloc(&dG, 2 * sizeof(GT)));
+            HIP_OK(hipMemcpy(dP, Ps, sizeof Ps, hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(dQ, Qs, sizeof Qs, hipMemcpyHostToDevice));
+            GT out[2], one, e = Pair({g1}, {g2});
+            one.Div(e, e);
+            for (int rep = 0; rep < 3; rep++) {
+                check(gpbc_multi_pair_hostseg_dev(dP, dQ, seg, 2, dG, st));
+                HIP_OK(hipMemcpy(out, dG, sizeof out, hipMemcpyDeviceToHost));
+                EXPECT(out[0].Equal(one) && !out[1].Equal(one));
+            }
+            check(gpbc_debug_stale_table_once());
+            EXPECT(gpbc_multi_pair_hostseg_dev(dP, dQ, seg, 2, dG, st) == GPBC_ERR_INTERNAL);
+            HIP_OK(hipMemcpy(out, dG, sizeof out, hipMemcpyDeviceToHost));
+            GT zero; std::memset(&zero, 0, sizeof zero);
+            EXPECT(out[0].Equal(zero) && out[1].Equal(zero));
+            check(gpbc_multi_pair_hostseg_dev(dP, dQ, seg, 2, dG, st));
+            HIP_OK(hipMemcpy(out, dG, sizeof out, hipMemcpyDeviceToHost));
+            EXPECT(out[0].Equal(one) && !out[1].Equal(one));
+            hipFree(dP); hipFree(dQ); hipFree(dG); hipStreamDestroy(st);
+            printf("hostseg_dev on a created stream: accepts, rejects, fails closed on a stale table\n");
+        }
     }
     check(gpbc_shutdown());
     printf("multi-device OK\n");

@@ -289,3 +289,17 @@ def test_bucket_msm_under_bounds(hc, oracle):
             out = np.zeros(w, dtype=np.uint8)
             hc.hc_msm(ctypes.c_int(1 if name == "g2" else 0), vp(B), vp(K), ctypes.c_size_t(n), ctypes.c_int(c), vp(out))
             assert (out == want).all(), (name, c)
+
+
+def test_executed_mad_counts_file_is_current(hc):
+    """profiles/executed_mads.json (what bench.py's `executed_mad_*` fields are computed from) equals the harness's count of the
+    MADs the device code issues per pairing / scalar multiplication (tests/executed_mads.py regenerates it)."""
+    import json
+    import executed_mads
+    hc.hc_mads_take.restype = ctypes.c_double
+    got = executed_mads.count(hc, n=4)                                       # the same four inputs the file was made from
+    doc = json.load(open(os.path.join(ROOT, "profiles", "executed_mads.json")))
+    for unit, want in doc["mads_per_unit"].items():
+        assert abs(got[unit] - want) <= 1, (unit, got[unit], want)
+    # the device does 81 limb products where SURVEY's nominal CIOS has 64, and lazy Fp2 products: more MADs than nominal for the pairing
+    assert doc["mads_per_unit"]["pairing"] > doc["nominal_mac_per_unit"]["pairing"]

@@ -381,6 +381,14 @@ void hc_msm(int g2, const uint8_t *B, const uint8_t *K, size_t n, int c, uint8_t
 }
 // worst-case figures since process start: [max |int64 column|, max limb bound, max value bound (units of p),
 // #products (fe_mul + fe_mul2), #norms, #fe_mul2, #reduces]  (out must hold 7 doubles)
+// v_mad_i64_i32 the device form of everything run since the last call would have executed (summed over the lanes of a pair)
+double hc_mads_take(void) {
+    stats_flush();
+    std::lock_guard<std::mutex> lk(g_stats_mu);
+    const double m = (double)g_stats_total.mads;
+    g_stats_total.mads = 0;
+    return m;
+}
 void hc_stats(double *out) {
     stats_flush();
     BoundStats &s = g_stats_total;

@@ -31,5 +31,16 @@ for k in agg:
         n=cnt[k]["FETCH_SIZE"]
         traffic[kk]={"fetch_kb": agg[k]["FETCH_SIZE"]/n, "write_kb": agg[k]["WRITE_SIZE"]/cnt[k]["WRITE_SIZE"], "batch": $B if n==1 else min($B,262144), "launches_per_batch": 1}
 json.dump(traffic, open(f"{R}/gpurun_out/{TAG}_traffic.json","w"), indent=1)
+# per-kernel instruction counts, independent of the box's clock: copy to profiles/pmc_counters.json for bench.py
+counters={"source": f"profiles/{TAG}_counters.json (tools/pmc_run.sh, batch $B per launch)", "kernels": {}}
+for k in agg:
+    kk=k.strip('"')
+    if not kk.startswith("k_") or "SQ_WAVES" not in agg[k]: continue
+    w=agg[k]["SQ_WAVES"]/cnt[k]["SQ_WAVES"]
+    g=lambda c: (agg[k][c]/cnt[k][c]) if c in agg[k] else None
+    counters["kernels"][kk]={"waves": w, "valu_instr_per_wave": g("SQ_INSTS_VALU")/w if g("SQ_INSTS_VALU") else None,
+        "wait_any_share_of_wave_cycles": g("SQ_WAIT_ANY")/g("SQ_WAVE_CYCLES") if g("SQ_WAIT_ANY") and g("SQ_WAVE_CYCLES") else None,
+        "vmem_instr_per_wave": ((g("SQ_INSTS_VMEM") or 0)+(g("SQ_INSTS_FLAT") or 0))/w, "lds_instr_per_wave": (g("SQ_INSTS_LDS") or 0)/w, "salu_instr_per_wave": (g("SQ_INSTS_SALU") or 0)/w}
+json.dump(counters, open(f"{R}/gpurun_out/{TAG}_counters.json","w"), indent=1)
 print(open(f"{R}/gpurun_out/{TAG}_summary.txt").read())
 PY

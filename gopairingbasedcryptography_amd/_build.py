@@ -36,6 +36,23 @@ def _stale():
         return f.read().strip() != _source_hash()
 
 
+def _check_isa(tmp):
+    """Refuse device code that contains v_subrev_*_dpp.  The compiler folds `a - swap(b)` (swap = a single-use DPP lane move) into
+    v_subrev_u32_dpp assuming src1 - dpp(src0); gfx950 computes dpp(src1) - src0 (tools/subdpp_probe.hip: every lane wrong, for the
+    compiler's output and for the hand-written instruction).  csrc/tower29_pair.hip.hpp subtracts on the sending lane instead; this
+    check keeps a later edit from re-introducing the pattern silently (the host interval harness has no DPP and cannot see it)."""
+    import glob
+    import re
+    bad = []
+    for f in glob.glob(os.path.join(tmp, "*", "*gfx950*.s")):
+        with open(f, errors="replace") as fh:
+            n = len(re.findall(r"^\s+v_subb?rev\w*_dpp\b", fh.read(), flags=re.M))
+        if n:
+            bad.append("%s: %d" % (os.path.basename(f), n))
+    if bad:
+        raise RuntimeError("device ISA contains v_subrev_*_dpp (wrong on gfx950, see _build._check_isa): " + ", ".join(bad))
+
+
 def build_library(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 -> gopairingbasedcryptography_amd/libgpbc_bn254.so; returns its path."""
     if not force and not _stale():
@@ -44,11 +61,13 @@ def build_library(force=False, verbose=False):
     with tempfile.TemporaryDirectory(prefix="gpbc_build_") as tmp:
         procs = []
         for s in SOURCES:
-            obj = os.path.join(tmp, s.replace(".hip", ".o"))
-            cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, s), "-o", obj]
+            unit = os.path.join(tmp, s.replace(".hip", ""))
+            os.makedirs(unit)
+            obj = os.path.join(unit, s.replace(".hip", ".o"))
+            cmd = [hipcc] + FLAGS + ["-save-temps", "-c", os.path.join(CSRC, s), "-o", obj]      # temps (the device ISA among them) land in cwd = unit
             if verbose:
                 print(" ".join(cmd))
-            procs.append((cmd, obj, subprocess.Popen(cmd)))
+            procs.append((cmd, obj, subprocess.Popen(cmd, cwd=unit, stderr=subprocess.DEVNULL if not verbose else None)))
         objs = []
         for cmd, obj, p in procs:
             if p.wait() != 0:
@@ -57,6 +76,7 @@ def build_library(force=False, verbose=False):
                         q.kill()
                 raise subprocess.CalledProcessError(p.returncode, cmd)
             objs.append(obj)
+        _check_isa(tmp)
         link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
             print(" ".join(link))

@@ -522,6 +522,34 @@ GPBC_INLINE Fe fe_reduce(const Fe &a) {
     return r;
 }
 
+// out = norm(3 t - 2 x - k p): the output step of a cyclotomic squaring (tower29_pair.hip.hpp) with the value reduction folded in
+// BEFORE the one normalisation.  t: carry-free normalised (limbs 0..7 within [-2^4, 2^29 + 2^4]); x: normalised the same way (so
+// -2x cannot push a limb below -2^30 - 2^5); the row k p has limbs in [0, 2^29): every limb of 3t - 2x - row stays inside
+// (-2^31, 2^31).  k comes from the un-normalised top limb — the carries still sitting in limb 7 are worth less than 2^-20 p.
+GPBC_INLINE Fe fe_cyclo_out(const Fe &t, const Fe &x) {
+    Fe w;
+#pragma unroll
+    for (int i = 0; i < NL; i++) w.v[i] = 3 * t.v[i] - 2 * x.v[i];
+    constexpr int32_t P8 = f29_p(NL - 1);
+    int32_t k = (int32_t)rintf((float)w.v[NL - 1] * (1.0f / (float)P8));
+    k = k < -256 ? -256 : (k > 256 ? 256 : k);
+    const int32_t *row = F29_KP[k + 256];
+#pragma unroll
+    for (int i = 0; i < NL; i++) w.v[i] -= row[i];
+#ifdef GPBC_BOUNDS
+    if (3 * t.vb + 2 * x.vb >= 256.0) bounds_fail("fe_cyclo_out input value", 3 * t.vb + 2 * x.vb, 256.0);
+    for (int i = 0; i < NL - 1; i++) {
+        w.lo[i] = 3 * t.lo[i] - 2 * x.hi[i] - (double)LMASK;
+        w.hi[i] = 3 * t.hi[i] - 2 * x.lo[i];
+    }
+    w.hi[NL - 1] = (double)P8 / 2 + 270; w.lo[NL - 1] = -w.hi[NL - 1];
+    w.vb = 0.51;
+    bound_stats().reduces++;
+    check_limbs(w, "fe_cyclo_out limb");
+#endif
+    return fe_norm(w);
+}
+
 // The same reduction with k*p formed arithmetically (nine 64-bit multiplies with splits, no memory access): used by the
 // Miller accumulator, whose memory pipeline is busy streaming the lines — there the table loads cost more than they save
 // (measured: k_miller_accumulate 14.6 -> 15.1 ms with the table, k_final_exp 77.6 -> 76.0 ms).

@@ -87,13 +87,9 @@ template <class X, class LineAt> GPBC_INLINE F6 miller_accumulate_multi_34(const
     return h;
 }
 
-// n squarings in place, each value-reduced once on its outputs (its xi products are only normalised)
-template <class X> GPBC_INLINE F6 f12p_cyclo_sqr_n(const X &x, F6 r, int n) {
-    for (int i = 0; i < n; i++) r = f12p_cyclo_sqr<true>(x, r);
-    return r;
-}
-
-// x^u with width-4 signed windows (see f12_expt_to)
+// x^u with width-4 signed windows (see f12_expt_to).  The squarings run in the alternating-sign form (f12p_cyclo_sqr_run): after an odd
+// number of them the lane pair holds the CONJUGATE of the running value; conj(r) conj(t) = conj(r t), so the window product takes the
+// table entry conjugated exactly when (digit negative) differs from (r conjugated), and one conjugation at the end restores the sign.
 template <class X> GPBC_NOINLINE void f12p_expt_to(const X &x, F6 &z, const F6 &b) {
     constexpr int8_t D[GPBC_U_WNAF4_LEN] = GPBC_U_WNAF4;
     F6 tab[4];
@@ -102,19 +98,20 @@ template <class X> GPBC_NOINLINE void f12p_expt_to(const X &x, F6 &z, const F6 &
     for (int k = 1; k < 4; k++) tab[k] = f12p_mul(x, tab[k - 1], b2);
     F6 r = tab[(D[GPBC_U_WNAF4_LEN - 1] - 1) / 2];
     int run = 0;
+    bool flipped = false;
     for (int i = GPBC_U_WNAF4_LEN - 2; i >= 0; i--) {
         run++;
         int d = D[i];
         if (d != 0) {
-            r = f12p_cyclo_sqr_n(x, r, run);
+            r = f12p_cyclo_sqr_run(x, r, run, flipped);
             run = 0;
             F6 t = tab[((d < 0 ? -d : d) - 1) / 2];
-            if (d < 0) t = f12p_conj(x, t);
+            if ((d < 0) != flipped) t = f12p_conj(x, t);
             r = f12p_mul(x, r, t);
         }
     }
-    if (run) r = f12p_cyclo_sqr_n(x, r, run);
-    z = r;
+    if (run) r = f12p_cyclo_sqr_run(x, r, run, flipped);
+    z = flipped ? f12p_conj(x, r) : r;
 }
 
 // x^(s (p^12-1)/r) on a lane pair; operation order of final_exp29

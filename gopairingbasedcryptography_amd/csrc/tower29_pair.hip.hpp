@@ -51,16 +51,16 @@ struct PairDpp {
         for (int i = 0; i < NL; i++) r.v[i] = a.v[i] * s;
         return r;
     }
-    // a + swap(b) in one instruction per limb (v_add_u32_dpp: the lane swap rides on the addition's first operand)
+    // a + swap(b): written limb by limb on a single-use swap, which the compiler folds into one v_add_u32_dpp per limb (it does so
+    // for Fe / F2-sized values; an F6-sized swap goes through memory first and is not folded).
+    // NEVER write a - swap(b) with a single-use swap: the compiler folds it into v_subrev_u32_dpp, and on gfx950 that instruction
+    // computes dpp(src1) - src0, not src1 - dpp(src0) as the compiler assumes (tools/subdpp_probe.hip: 64 of 64 lanes wrong, for the
+    // compiler's own output and for the hand-written instruction alike; v_sub_u32_dpp and v_add_u32_dpp are fine).  Subtract on the
+    // SENDING lane instead — a + swap(c - b) — and _build.py refuses a library whose ISA contains v_subrev_*_dpp.
     __device__ __forceinline__ Fe add_swap(const Fe &a, const Fe &b) const {
         Fe r;
-#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-        for (int i = 0; i < NL; i++)
-            asm("v_add_u32_dpp %0, %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(r.v[i]) : "v"(b.v[i]), "v"(a.v[i]));
-#else
-        r = a;
-#endif
+        for (int i = 0; i < NL; i++) r.v[i] = a.v[i] + sw(b.v[i]);
         return r;
     }
 };
@@ -70,6 +70,10 @@ template <class X> GPBC_INLINE F2 f2p_sgn(const X &x, const F2 &a) { return F2{x
 template <class X> GPBC_INLINE F6 f6p_sgn(const X &x, const F6 &a) { return F6{f2p_sgn(x, a.b0), f2p_sgn(x, a.b1), f2p_sgn(x, a.b2)}; }
 template <class X> GPBC_INLINE F2 f2p_add_swap(const X &x, const F2 &a, const F2 &b) { return F2{x.add_swap(a.a0, b.a0), x.add_swap(a.a1, b.a1)}; }
 template <class X> GPBC_INLINE F6 f6p_add_swap(const X &x, const F6 &a, const F6 &b) { return F6{f2p_add_swap(x, a.b0, b.b0), f2p_add_swap(x, a.b1, b.b1), f2p_add_swap(x, a.b2, b.b2)}; }
+
+template <class X> GPBC_INLINE F6 f6p_add_partner(const X &x, const F6 &a) {
+    return F6{f2_add(a.b0, x.swap(a.b0)), f2_add(a.b1, x.swap(a.b1)), f2_add(a.b2, x.swap(a.b2))};
+}
 
 // (C0 on even, C1 on odd) <- one()
 template <class X> GPBC_INLINE F6 f12p_one(const X &x) { return f6_sel(x.odd, F6{f2_zero(), f2_zero(), f2_zero()}, F6{f2_one(), f2_zero(), f2_zero()}); }
@@ -94,9 +98,10 @@ template <class X> GPBC_INLINE F6 f12p_mul_034(const X &x, const F6 &h, const F2
     F2 s34 = f2_norm(f2_add(c3, c4));
     F6 r0 = f6_mul_f2(h, c0);
     F6 r1 = f6_mul_01_t<false, false>(h, c3, c4, s34);       // b0, b1 un-normalised: they only enter the sum below
-    F6 p1 = x.swap(r1);
-    F6 add = f6_sel(x.odd, p1, f6_mul_v_t<false>(p1));
-    return f6_reduce_arith(f6_norm(f6_add(r0, add)));                    // the one value reduction of this step (no table loads
+    // each lane sends what its partner adds — the odd lane v (b l1), the even lane a l1 — so the received value has one use and
+    // rides on the addition (v_add_u32_dpp) instead of costing a move per limb
+    F6 send = f6_sel(x.odd, f6_mul_v_t<false>(r1), r1);
+    return f6_reduce_arith(f6_norm(f6p_add_swap(x, r0, send)));          // the one value reduction of this step (no table loads
                                                                          // here: this runs beside the lines stream, see fe29.hip.hpp)
 }
 
@@ -105,9 +110,8 @@ template <class X> GPBC_INLINE F6 f12p_mul_034(const X &x, const F6 &h, const F2
 template <class X> GPBC_INLINE F6 f12p_mul_34(const X &x, const F6 &h, const F2 &c3, const F2 &c4) {
     F2 s34 = f2_norm(f2_add(c3, c4));
     F6 r1 = f6_mul_01_t<false, false>(h, c3, c4, s34);
-    F6 p1 = x.swap(r1);
-    F6 add = f6_sel(x.odd, p1, f6_mul_v_t<false>(p1));
-    return f6_reduce_arith(f6_norm(f6_add(h, add)));
+    F6 send = f6_sel(x.odd, f6_mul_v_t<false>(r1), r1);       // as in f12p_mul_034
+    return f6_reduce_arith(f6_norm(f6p_add_swap(x, h, send)));
 }
 
 // Product of two lines, (c0 + (c3 + c4 v) w)(d0 + (d3 + d4 v) w), as a lane-pair value:
@@ -170,19 +174,29 @@ struct F6Park {                                               // host / A-B buil
 };
 #endif
 
-// full product (Karatsuba over F6).  The third product (a0+a1)(b0+b1) is itself split: the even lane computes its three
-// diagonal F2 products, the odd lane its three cross products.
+// full product (Karatsuba over F6).  The third product (a0+a1)(b0+b1) = sx * sy is itself split over the pair, 2 + 2 operand sums:
+//   even lane  u0 = sx0 sy0,  u1 = sx1 sy1,  m01 = (sx0+sx1)(sy0+sy1)        odd lane  u2 = sx2 sy2,  m12 = (sx1+sx2)(sy1+sy2),  m02 = (sx0+sx2)(sy0+sy2)
+// (with all three cross products on one lane that lane needed three sums per operand and the other none — but both lanes execute
+// every instruction, so the split that minimises the sums of the busier lane wins: 4 instead of 6 add-and-normalise per product).
+// (Leaving the outputs un-reduced for the squarings that follow in x^u does not work: the squares of an un-reduced value break the
+// 2^28 top-limb guard of the product routine — the interval harness rejects it.)
 template <class X> GPBC_INLINE F6 f12p_mul(const X &x, const F6 &hx, const F6 &hy) {
     const F6Park parked(f6_mul_t<false>(hx, hy));            // even: t0 = a0 b0, odd: t1 = a1 b1 — needed again after the three products below
-    F6 sx = f6_norm(f6_add(hx, x.swap(hx)));                // (a DPP-fused addition here measured 3 % SLOWER: the 108 inline-asm
-    F6 sy = f6_norm(f6_add(hy, x.swap(hy)));                //  statements get in the scheduler's way; profiles/r02_microbench_pair.txt)
-    // three F2 products per lane of sx * sy
-    F2 xa = f2_sel(x.odd, f2_norm(f2_add(sx.b1, sx.b2)), sx.b0), ya = f2_sel(x.odd, f2_norm(f2_add(sy.b1, sy.b2)), sy.b0);
-    F2 xb = f2_sel(x.odd, f2_norm(f2_add(sx.b0, sx.b1)), sx.b1), yb = f2_sel(x.odd, f2_norm(f2_add(sy.b0, sy.b1)), sy.b1);
-    F2 xc = f2_sel(x.odd, f2_norm(f2_add(sx.b0, sx.b2)), sx.b2), yc = f2_sel(x.odd, f2_norm(f2_add(sy.b0, sy.b2)), sy.b2);
-    F6 mine{f2_mul(xa, ya), f2_mul(xb, yb), f2_mul(xc, yc)};  // even: (u0,u1,u2) diagonal, odd: (m12,m01,m02) cross
+    // own + partner's half, coefficient by coefficient: with the swap taken per F2 the compiler folds the DPP move into the addition
+    // (v_add_u32_dpp) — on a whole F6 it does not (the 216-byte aggregate goes through memory first), and hand-written
+    // v_add_u32_dpp statements had measured 3 % slower (profiles/r02_microbench_pair.txt)
+    F6 sx = f6_norm(f6p_add_partner(x, hx));
+    F6 sy = f6_norm(f6p_add_partner(x, hy));
+    F2 xa = f2_sel(x.odd, sx.b2, sx.b0), ya = f2_sel(x.odd, sy.b2, sy.b0);                                   // u0 | u2
+    F2 xb = f2_norm(f2_add(sx.b1, f2_sel(x.odd, sx.b2, f2_zero()))), yb = f2_norm(f2_add(sy.b1, f2_sel(x.odd, sy.b2, f2_zero())));   // u1 | m12
+    F2 xc = f2_norm(f2_add(sx.b0, f2_sel(x.odd, sx.b2, sx.b1))), yc = f2_norm(f2_add(sy.b0, f2_sel(x.odd, sy.b2, sy.b1)));           // m01 | m02
+    F6 mine{f2_mul(xa, ya), f2_mul(xb, yb), f2_mul(xc, yc)};  // even: (u0, u1, m01)   odd: (u2, m12, m02)
     F6 other = x.swap(mine);
-    F6 dg = f6_sel(x.odd, other, mine), cr = f6_sel(x.odd, mine, other);
+    // (u0, u1, u2) and (m12, m01, m02) AS THE ODD LANE SEES THEM — only the odd lane's output uses the third product (the even
+    // lane's is t0 + v t1), so no select is spent on making the even lane's copy right; its values are products like any other
+    // and go through the same arithmetic unused
+    F6 dg{other.b0, other.b1, mine.b0};
+    F6 cr{mine.b1, other.b2, mine.b2};
     F6 t = parked.get();
     F6 pt = x.swap(t);                                        // even: t1, odd: t0
     // one shared xi-multiplication: the odd lane needs xi (m12 - u1 - u2) for m, the even lane xi t1.b2 for v t1
@@ -233,6 +247,53 @@ template <bool REDUCE, class X> GPBC_INLINE F6 f12p_cyclo_sqr(const X &x, const 
          f2_norm(f2_add(f2_dbl(f2_norm(f2_add(tt1, sgn.b1))), tt1)),
          f2_norm(f2_add(f2_dbl(f2_norm(f2_add(tt2, sgn.b2))), tt2))};
     return REDUCE ? f6_reduce(r) : r;
+}
+
+// The same squaring for RUNS of squarings (x^u: 62 of them in runs of ~4), with the odd lane's sign ALTERNATING: the caller passes
+// C1 on the odd lane as s = sigma C1 and gets back -sigma C1' — the conjugate of the square when sigma = +1.  Why: the Granger-Scott
+// output is 3 T(x) - 2 conj(x), minus on the C0 half and plus on the C1 half; the C1 half of T is bilinear in (C0, C1), so with
+// s in place of C1 the same code yields sigma T, its negative costs nothing (the differences are formed in the other order), and
+// 3 (-sigma T) - 2 s = -sigma (3 T + 2 C1): BOTH lanes evaluate 3 tt - 2 h.  That removes the per-lane sign (54 multiplications
+// by +-1 per squaring) and, with the operand normalised non-negative, lets the value reduction go in front of ONE normalisation
+// (fe_cyclo_out) instead of two normalisations and a reduction after them: ~260 of ~3 700 instructions per squaring.
+// Conjugation is a ring automorphism, so products are taken with the operand conjugated alike (f12p_expt_to tracks the parity).
+// h: normalised by fe_norm as its last step (limbs 0..7 within [-2^4, 2^29 + 2^4]) and value-reduced — outputs of this function
+// qualify, anything else goes through f6_norm first (f12p_cyclo_sqr_run).
+template <class X> GPBC_INLINE F6 f12p_cyclo_sqr_alt(const X &x, const F6 &h) {
+    F2 q0 = f2_sqr(h.b0), q1 = f2_sqr(h.b1), q2 = f2_sqr(h.b2);        // even: t1,t5,t2   odd: t3,t0,t4  (squares: sign-free)
+    F2 sa = f2_sqr_n(f2p_add_swap(x, f2_sel(x.odd, h.b2, h.b0), h.b1));   // even: s6   odd: s8   (own + partner's b1)
+    // C0.b2 + s.b0 on both lanes: each lane's own term is exactly what the partner needs (even: b2, odd: b0) — one select, one
+    // swap-and-add
+    F2 own = f2_sel(x.odd, h.b0, h.b2);
+    F2 u = f2_norm(f2p_add_swap(x, own, own));
+    // the NEGATED ninth square, -s7 = -(u0^2 - u1^2) - 2 u0 u1 i: the even lane forms (u0 + u1)(u1 - u0), the odd lane (2 u0)(-u1).  Negated
+    // because only the odd lane's tt2 = t2 + t3 - s7 uses it and the partner's half must enter that sum by an ADDITION (see add_swap)
+    Fe nhalf = fe_mul(fe_sel(x.odd, fe_dbl(u.a0), fe_add(u.a0, u.a1)), fe_sel(x.odd, fe_neg(u.a1), fe_sub(u.a1, u.a0)));
+    F2 A = f2_mul_xi(q2);                                                 // even: xi t2   odd: xi t4
+    // Every exchange below is "each lane sends what its partner needs", so that the received value has ONE use and rides on an
+    // addition (f2p_add_swap) instead of costing a move of its own; where the partner must subtract, the SENDER subtracts:
+    //   Y = q1 + partner's ((even lane receives q2 | odd lane receives q0) - sa)    even: t5 + t4 - s8 = -sigma x the cross term of the odd
+    //                                                                                 lane's first coefficient (before xi)   odd: t0 + t1 - s6 = tt1
+    //   Z = (even: A | odd: t3 - s7) + partner's (even receives q0 | odd receives q2) even: xi t2 + t3 = tt1                 odd: t2 + t3 - s7 = tt2
+    F2 Y = f2p_add_swap(x, q1, f2_sub(f2_sel(x.odd, q2, q0), sa));
+    F2 ns7{x.add_swap(q0.a0, nhalf), fe_add(q0.a1, nhalf)};               // odd lane: t3 - s7 (real part of -s7 from the partner, own imaginary part)
+    F2 Z = f2p_add_swap(x, f2_sel(x.odd, ns7, A), f2_sel(x.odd, q0, q2));
+    F2 B = f2_mul_xi(f2_sel(x.odd, q1, f2_norm(Y)));                      // even: xi (t4 + t5 - s8)   odd: xi t0
+    F2 tt0 = f2_norm(f2p_add_swap(x, f2_sel(x.odd, f2_zero(), q0), B));   // even: xi t0 + t1          odd: -sigma xi (cross)
+    F2 tt1 = f2_norm(f2_sel(x.odd, Y, Z));
+    F2 tt2 = f2_norm(f2_sel(x.odd, Z, f2p_add_swap(x, q1, A)));          // even: xi t4 + t5
+    return F6{F2{fe_cyclo_out(tt0.a0, h.b0.a0), fe_cyclo_out(tt0.a1, h.b0.a1)},
+              F2{fe_cyclo_out(tt1.a0, h.b1.a0), fe_cyclo_out(tt1.a1, h.b1.a1)},
+              F2{fe_cyclo_out(tt2.a0, h.b2.a0), fe_cyclo_out(tt2.a1, h.b2.a1)}};
+}
+// n squarings in a row.  `flipped` is the parity the caller tracks: false = the odd lane holds C1, true = it holds -C1 (the value
+// is the conjugate of what the pair nominally represents).  Any N-class input is accepted (one normalisation up front).
+template <class X> GPBC_INLINE F6 f12p_cyclo_sqr_run(const X &x, F6 r, int n, bool &flipped) {
+    if (n <= 0) return r;
+    r = f6_norm(r);
+    for (int i = 0; i < n; i++) r = f12p_cyclo_sqr_alt(x, r);
+    flipped ^= (bool)(n & 1);
+    return r;
 }
 
 // x^(p^j): coefficient of w^k -> (conj if j odd)(g_k) * gamma_j[k]; even lane k = 0,2,4, odd lane k = 1,3,5

@@ -1,11 +1,11 @@
 // Micro-benchmark of the lane-pair Fp12 primitives (csrc/tower29_pair.hip.hpp) on gfx950: SIMD cycles per wave-call of
 // f12p_cyclo_sqr / f12p_mul / f12p_sqr / f12p_mul_034 and of the F2 leaves at 2 waves per SIMD, beside the cycles their
 // MAD instructions alone would take (4.5 cycles per wave-instruction, profiles/r01_microbench_valu.txt).
-// build: hipcc -O3 --offload-arch=gfx950 -std=c++17 tools/microbench_pair.hip -o tools/microbench_pair
+// build: hipcc -O3 --offload-arch=gfx950 -std=c++17 -I gopairingbasedcryptography_amd/csrc tools/microbench_pair.hip -o tools/microbench_pair
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
-#include "../gopairingbasedcryptography_amd/csrc/tower29_pair.hip.hpp"
+#include "tower29_pair.hip.hpp"      // build with -I <csrc dir>: the tree's or a variant copy's
 using namespace gpbc;
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
@@ -31,6 +31,7 @@ __global__ void __launch_bounds__(64, 2) bench(const uint8_t *in, uint8_t *out, 
         else if (OP == 8) { F12 z = f12_cyclo_sqr(F12{h, g}); h = z.c0; g = z.c1; }
         else if (OP == 9) { F12 z = f12_mul(F12{h, g}, F12{g, h}); h = z.c0; g = z.c1; }
         else if (OP == 10) { F12 z = f12_sqr(F12{h, g}); h = f6_reduce(z.c0); g = f6_reduce(z.c1); }
+        else if (OP == 11) h = f12p_cyclo_sqr_alt(x, h);          // the alternating-sign form used inside runs (x^u)
     }
     uint8_t *o = out + 384 * (i & 63);
     if (OP >= 8) h = f6_norm(f6_add(h, g));
@@ -59,6 +60,7 @@ int main() {
     CHECK(hipMemcpy(din, h, sizeof h, hipMemcpyHostToDevice));
     for (int w : {2, 1}) {
         run<0>("f12p_cyclo_sqr (4.5 F2 sqr)", din, dout, ncu, w, 400, 4.5 * 324);
+        run<11>("f12p_cyclo_sqr_alt (run form)", din, dout, ncu, w, 400, 4.5 * 324);
         run<1>("f12p_mul (9 F2 mul)", din, dout, ncu, w, 200, 9 * 486);
         run<2>("f12p_sqr (6 F2 mul) + reduce", din, dout, ncu, w, 200, 6 * 486);
         run<3>("f12p_mul_034 (8 F2 mul)", din, dout, ncu, w, 200, 8 * 486);

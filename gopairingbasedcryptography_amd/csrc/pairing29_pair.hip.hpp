@@ -92,10 +92,12 @@ template <class X, class LineAt> GPBC_INLINE F6 miller_accumulate_multi_34(const
 // table entry conjugated exactly when (digit negative) differs from (r conjugated), and one conjugation at the end restores the sign.
 template <class X> GPBC_NOINLINE void f12p_expt_to(const X &x, F6 &z, const F6 &b) {
     constexpr int8_t D[GPBC_U_WNAF4_LEN] = GPBC_U_WNAF4;
+    // the table entries are kept positive-normalised (one f6_norm each): the window products then run in the subtractive-Karatsuba form
+    // (f12p_mul<true>) — their other operand comes out of a squaring run, which ends in a normalisation
     F6 tab[4];
-    tab[0] = b;
+    tab[0] = f6_norm(b);
     F6 b2 = f12p_cyclo_sqr<true>(x, b);
-    for (int k = 1; k < 4; k++) tab[k] = f12p_mul(x, tab[k - 1], b2);
+    for (int k = 1; k < 4; k++) tab[k] = f6_norm(f12p_mul(x, tab[k - 1], b2));
     F6 r = tab[(D[GPBC_U_WNAF4_LEN - 1] - 1) / 2];
     int run = 0;
     bool flipped = false;
@@ -106,8 +108,8 @@ template <class X> GPBC_NOINLINE void f12p_expt_to(const X &x, F6 &z, const F6 &
             r = f12p_cyclo_sqr_run(x, r, run, flipped);
             run = 0;
             F6 t = tab[((d < 0 ? -d : d) - 1) / 2];
-            if ((d < 0) != flipped) t = f12p_conj(x, t);
-            r = f12p_mul(x, r, t);
+            if ((d < 0) != flipped) t = f6_norm(f12p_conj(x, t));       // (the negated half normalises to non-negative limbs again)
+            r = f12p_mul<true>(x, r, t);
         }
     }
     if (run) r = f12p_cyclo_sqr_run(x, r, run, flipped);

@@ -176,21 +176,26 @@ struct F6Park {                                               // host / A-B buil
 
 // full product (Karatsuba over F6).  The third product (a0+a1)(b0+b1) = sx * sy is itself split over the pair, 2 + 2 operand sums:
 //   even lane  u0 = sx0 sy0,  u1 = sx1 sy1,  m01 = (sx0+sx1)(sy0+sy1)        odd lane  u2 = sx2 sy2,  m12 = (sx1+sx2)(sy1+sy2),  m02 = (sx0+sx2)(sy0+sy2)
-// (with all three cross products on one lane that lane needed three sums per operand and the other none — but both lanes execute
-// every instruction, so the split that minimises the sums of the busier lane wins: 4 instead of 6 add-and-normalise per product).
+// (with all three cross products on one lane that lane needed three operand combinations per side and the other none — but both
+// lanes execute every instruction, so the split that minimises the work of the busier lane wins).
 // (Leaving the outputs un-reduced for the squarings that follow in x^u does not work: the squares of an un-reduced value break the
 // 2^28 top-limb guard of the product routine — the interval harness rejects it.)
-template <class X> GPBC_INLINE F6 f12p_mul(const X &x, const F6 &hx, const F6 &hy) {
-    const F6Park parked(f6_mul_t<false>(hx, hy));            // even: t0 = a0 b0, odd: t1 = a1 b1 — needed again after the three products below
+// PN = true: both operands are positive-normalised (straight out of fe_norm / f6_norm; see f6_mul_pn_t) and the own-half product takes
+// the subtractive form as well.
+template <bool PN = false, class X> GPBC_INLINE F6 f12p_mul(const X &x, const F6 &hx, const F6 &hy) {
+    const F6Park parked(PN ? f6_mul_pn_t<false>(hx, hy) : f6_mul_t<false>(hx, hy));   // even: t0 = a0 b0, odd: t1 = a1 b1 — needed again after the three products below
     // own + partner's half, coefficient by coefficient: with the swap taken per F2 the compiler folds the DPP move into the addition
     // (v_add_u32_dpp) — on a whole F6 it does not (the 216-byte aggregate goes through memory first), and hand-written
     // v_add_u32_dpp statements had measured 3 % slower (profiles/r02_microbench_pair.txt)
     F6 sx = f6_norm(f6p_add_partner(x, hx));
     F6 sy = f6_norm(f6p_add_partner(x, hy));
+    // The cross products in SUBTRACTIVE Karatsuba form, m_ij' = (x_i - x_j)(y_i - y_j) = u_i + u_j - (x_i y_j + x_j y_i): sx and sy were
+    // just normalised (limbs 0..7 non-negative), so a DIFFERENCE of two coefficients stays within +-(2^29 + small) and needs no
+    // normalisation of its own — the sums (x_i + x_j) of the additive form did (four per product, ~190 instructions).
     F2 xa = f2_sel(x.odd, sx.b2, sx.b0), ya = f2_sel(x.odd, sy.b2, sy.b0);                                   // u0 | u2
-    F2 xb = f2_norm(f2_add(sx.b1, f2_sel(x.odd, sx.b2, f2_zero()))), yb = f2_norm(f2_add(sy.b1, f2_sel(x.odd, sy.b2, f2_zero())));   // u1 | m12
-    F2 xc = f2_norm(f2_add(sx.b0, f2_sel(x.odd, sx.b2, sx.b1))), yc = f2_norm(f2_add(sy.b0, f2_sel(x.odd, sy.b2, sy.b1)));           // m01 | m02
-    F6 mine{f2_mul(xa, ya), f2_mul(xb, yb), f2_mul(xc, yc)};  // even: (u0, u1, m01)   odd: (u2, m12, m02)
+    F2 xb = f2_sub(sx.b1, f2_sel(x.odd, sx.b2, f2_zero())), yb = f2_sub(sy.b1, f2_sel(x.odd, sy.b2, f2_zero()));   // u1 | m12' = (x1 - x2)(y1 - y2)
+    F2 xc = f2_sub(sx.b0, f2_sel(x.odd, sx.b2, sx.b1)), yc = f2_sub(sy.b0, f2_sel(x.odd, sy.b2, sy.b1));           // m01' = (x0 - x1)(y0 - y1) | m02' = (x0 - x2)(y0 - y2)
+    F6 mine{f2_mul(xa, ya), f2_mul(xb, yb), f2_mul(xc, yc)};  // even: (u0, u1, m01')   odd: (u2, m12', m02')
     F6 other = x.swap(mine);
     // (u0, u1, u2) and (m12, m01, m02) AS THE ODD LANE SEES THEM — only the odd lane's output uses the third product (the even
     // lane's is t0 + v t1), so no select is spent on making the even lane's copy right; its values are products like any other
@@ -200,16 +205,15 @@ template <class X> GPBC_INLINE F6 f12p_mul(const X &x, const F6 &hx, const F6 &h
     F6 t = parked.get();
     F6 pt = x.swap(t);                                        // even: t1, odd: t0
     // one shared xi-multiplication: the odd lane needs xi (m12 - u1 - u2) for m, the even lane xi t1.b2 for v t1
-    F2 xi1 = f2_mul_xi_nn(f2_sel(x.odd, f2_norm(f2_sub(f2_sub(cr.b0, dg.b1), dg.b2)), pt.b2));
-    F2 m0 = f2_add(xi1, dg.b0);
-    F2 m1 = f2_add(f2_sub(f2_sub(cr.b1, dg.b0), dg.b1), f2_mul_xi_nn(dg.b2));
-    F2 m2 = f2_add(f2_sub(f2_sub(cr.b2, dg.b0), dg.b2), dg.b1);
-    F6 m{m0, m1, m2};                                         // (a0+a1)(b0+b1): meaningful on the odd lane.  None of the three is
-                                                              // normalised: their limbs lie within [-2^30 + 2, 2^30 + 2^29] and the
-                                                              // three-term difference below stays inside int32 (lowest value exactly
-                                                              // -2^31; proved by the interval harness, tools/bounds_check.cpp)
+    // (cross terms: x_i y_j + x_j y_i = u_i + u_j - m_ij')
+    F2 xi1 = f2_mul_xi_nn(f2_sel(x.odd, f2_norm(f2_sub(f2_add(dg.b1, dg.b2), cr.b0)), pt.b2));
+    // odd lane: (a0+a1)(b0+b1) - t0 - t1, coefficient by coefficient; additions and subtractions alternate so that every intermediate
+    // stays inside int32 (products have limbs 0..7 in [0, 2^29); the interval harness checks the order)
+    F2 o0 = f2_sub(f2_add(f2_sub(xi1, pt.b0), dg.b0), t.b0);
+    F2 o1 = f2_sub(f2_add(f2_sub(f2_add(f2_sub(dg.b0, cr.b1), dg.b1), pt.b1), f2_mul_xi_nn(dg.b2)), t.b1);
+    F2 o2 = f2_sub(f2_add(f2_sub(f2_add(f2_sub(dg.b0, cr.b2), dg.b2), pt.b2), dg.b1), t.b2);
+    F6 odd_out{o0, o1, o2};                                   // m - t0 - t1
     F6 even_out = f6_add(t, F6{xi1, pt.b0, pt.b1});           // t0 + v t1
-    F6 odd_out = f6_sub(f6_sub(m, pt), t);                    // m - t0 - t1
     return f6_reduce(f6_norm(f6_sel(x.odd, odd_out, even_out)));
 }
 

@@ -40,7 +40,7 @@ for k in agg:
     g=lambda c: (agg[k][c]/cnt[k][c]) if c in agg[k] else None
     counters["kernels"][kk]={"waves": w, "valu_instr_per_wave": g("SQ_INSTS_VALU")/w if g("SQ_INSTS_VALU") else None,
         "wait_any_share_of_wave_cycles": g("SQ_WAIT_ANY")/g("SQ_WAVE_CYCLES") if g("SQ_WAIT_ANY") and g("SQ_WAVE_CYCLES") else None,
-        "vmem_instr_per_wave": ((g("SQ_INSTS_VMEM") or 0)+(g("SQ_INSTS_FLAT") or 0))/w, "lds_instr_per_wave": (g("SQ_INSTS_LDS") or 0)/w, "salu_instr_per_wave": (g("SQ_INSTS_SALU") or 0)/w}
+        "vmem_instr_per_wave": (g("SQ_INSTS_VMEM") or 0)/w, "lds_instr_per_wave": (g("SQ_INSTS_LDS") or 0)/w, "salu_instr_per_wave": (g("SQ_INSTS_SALU") or 0)/w}
 json.dump(counters, open(f"{R}/gpurun_out/{TAG}_counters.json","w"), indent=1)
 print(open(f"{R}/gpurun_out/{TAG}_summary.txt").read())
 PY

@@ -580,6 +580,34 @@ GPBC_INLINE Fe fe_reduce_arith(const Fe &a) {
     return r;
 }
 
+// norm(a - k p) with k p formed arithmetically: the value reduction IN FRONT of the normalisation, so that the result comes out of
+// fe_norm (limbs 0..7 non-negative, "positive-normalised": what the subtractive Karatsuba forms of the towers need) instead of out
+// of a subtraction (signed limbs).  a: any limbs for which a_i - 2^29 - carry stays inside int32 (the interval harness checks);
+// k from the un-normalised top limb — what still sits in the lower limbs as carries is worth less than 2^-20 p.
+GPBC_INLINE Fe fe_reduce_arith_norm(const Fe &a) {
+    constexpr int32_t P8 = f29_p(NL - 1);
+    int32_t k = (int32_t)rintf((float)a.v[NL - 1] * (1.0f / (float)P8));
+    GPBC_B(bound_stats().mads += NL;)
+    Fe r;
+    int32_t hi_prev = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        int64_t t = (int64_t)k * (int64_t)f29_p(i);
+        int32_t lo = (int32_t)(t & LMASK), hi = (int32_t)(t >> LB);
+        r.v[i] = (i < NL - 1) ? a.v[i] - lo - hi_prev : a.v[i] - (int32_t)t - hi_prev;
+        hi_prev = hi;
+    }
+#ifdef GPBC_BOUNDS
+    if (a.vb >= 256.0) bounds_fail("fe_reduce_arith_norm input value", a.vb, 256.0);
+    for (int i = 0; i < NL - 1; i++) { r.lo[i] = a.lo[i] - (double)LMASK - 257; r.hi[i] = a.hi[i] + 257; }
+    r.hi[NL - 1] = (double)P8 / 2 + 270; r.lo[NL - 1] = -r.hi[NL - 1];
+    r.vb = 0.51;
+    bound_stats().reduces++;
+    check_limbs(r, "fe_reduce_arith_norm limb");
+#endif
+    return fe_norm(r);
+}
+
 // ------------------------------------------------------------------------------------------------ canonical form, I/O
 // Fully reduce to [0,p) with limbs in [0,2^29) (limb 8 < 2^24). Input value must lie in (-4p, 4p).
 GPBC_INLINE Fe fe_canonical(const Fe &a) {

@@ -13,22 +13,24 @@ namespace gpbc {
 // of two pairs, was measured on this kernel and is SLOWER here: k_miller_accumulate 56.9 -> 67.1 ms per 2^20 pairings — the 23
 // extra inlined full products and value reductions cost more in registers and code than the 4 F2 products they save.)
 template <class X, class Src> GPBC_INLINE F6 miller_accumulate_pair(const X &x, Src &&next) {
+    // the accumulator stays positive-normalised throughout (PN forms: every step ends in a normalisation), so the F6 products inside
+    // run in the subtractive Karatsuba form with no operand normalisations
     LineS l0 = next();
-    F6 h = f6_sel(x.odd, F6{l0.c3, l0.c4, f2_zero()}, F6{l0.c0, f2_zero(), f2_zero()});
+    F6 h = f6_norm(f6_sel(x.odd, F6{l0.c3, l0.c4, f2_zero()}, F6{l0.c0, f2_zero(), f2_zero()}));
     for (int i = BN254_ATE_NAF_LEN - 2; i >= 0; i--) {
         if (i != BN254_ATE_NAF_LEN - 2) {
-            h = f12p_sqr(x, h);
+            h = f12p_sqr<true>(x, h);
             LineS l = next();
-            h = f12p_mul_034(x, h, l.c0, l.c3, l.c4);
+            h = f12p_mul_034<true>(x, h, l.c0, l.c3, l.c4);
         }
         if (ate_naf_digit(i) != 0) {
             LineS l = next();
-            h = f12p_mul_034(x, h, l.c0, l.c3, l.c4);
+            h = f12p_mul_034<true>(x, h, l.c0, l.c3, l.c4);
         }
     }
     for (int k = 0; k < 2; k++) {
         LineS l = next();
-        h = f12p_mul_034(x, h, l.c0, l.c3, l.c4);
+        h = f12p_mul_034<true>(x, h, l.c0, l.c3, l.c4);
     }
     return h;
 }
@@ -72,15 +74,15 @@ struct Line34 { F2 c3, c4; };
 template <class X, class LineAt> GPBC_INLINE F6 miller_accumulate_multi_34(const X &x, int m, LineAt &&line) {
     int li = 0;
     auto mul_lines = [&](F6 h, int from) {
-        for (int p = from; p < m; p++) { Line34 l = line(p, li); h = f12p_mul_34(x, h, l.c3, l.c4); }
+        for (int p = from; p < m; p++) { Line34 l = line(p, li); h = f12p_mul_34<true>(x, h, l.c3, l.c4); }
         li++;
         return h;
     };
     Line34 l0 = line(0, li);
-    F6 h = f6_sel(x.odd, F6{l0.c3, l0.c4, f2_zero()}, F6{f2_one(), f2_zero(), f2_zero()});
+    F6 h = f6_norm(f6_sel(x.odd, F6{l0.c3, l0.c4, f2_zero()}, F6{f2_one(), f2_zero(), f2_zero()}));   // positive-normalised from here on (PN forms)
     h = mul_lines(h, 1);
     for (int i = BN254_ATE_NAF_LEN - 2; i >= 0; i--) {
-        if (i != BN254_ATE_NAF_LEN - 2) h = mul_lines(f12p_sqr(x, h), 0);
+        if (i != BN254_ATE_NAF_LEN - 2) h = mul_lines(f12p_sqr<true>(x, h), 0);
         if (ate_naf_digit(i) != 0) h = mul_lines(h, 0);
     }
     for (int k = 0; k < 2; k++) h = mul_lines(h, 0);

@@ -148,6 +148,8 @@ GPBC_INLINE F6 f6_norm(const F6 &x) { return F6{f2_norm(x.b0), f2_norm(x.b1), f2
 GPBC_INLINE F6 f6_reduce(const F6 &x) { return F6{f2_reduce(x.b0), f2_reduce(x.b1), f2_reduce(x.b2)}; }
 GPBC_INLINE F2 f2_reduce_arith(const F2 &x) { return F2{fe_reduce_arith(x.a0), fe_reduce_arith(x.a1)}; }
 GPBC_INLINE F6 f6_reduce_arith(const F6 &x) { return F6{f2_reduce_arith(x.b0), f2_reduce_arith(x.b1), f2_reduce_arith(x.b2)}; }
+GPBC_INLINE F2 f2_reduce_arith_norm(const F2 &x) { return F2{fe_reduce_arith_norm(x.a0), fe_reduce_arith_norm(x.a1)}; }
+GPBC_INLINE F6 f6_reduce_arith_norm(const F6 &x) { return F6{f2_reduce_arith_norm(x.b0), f2_reduce_arith_norm(x.b1), f2_reduce_arith_norm(x.b2)}; }
 // x * v: (xi b2, b0, b1); N-class in and out
 template <bool RX> GPBC_INLINE F6 f6_mul_v_t(const F6 &x) { return F6{f2_mul_xi_t<RX>(x.b2), x.b0, x.b1}; }
 GPBC_INLINE F6 f6_mul_v(const F6 &x) { return f6_mul_v_t<true>(x); }
@@ -203,6 +205,17 @@ template <bool RX, bool NORM01 = true> GPBC_INLINE F6 f6_mul_01_t(const F6 &x, c
     return F6{NORM01 ? f2_norm(t0) : t0, t1, f2_norm(t2)};    // t1 = m - a - b stays within (-2^30, 2^29): every caller only adds it
 }
 GPBC_INLINE F6 f6_mul_01(const F6 &x, const F2 &c0, const F2 &c1, const F2 &s01) { return f6_mul_01_t<true>(x, c0, c1, s01); }
+// The same sparse product for a positive-normalised x (see f6_mul_pn_t), subtractive form: the caller supplies d01 = norm(c0 - c1);
+//   x2 c1 = b - (x1 - x2) c1,   x0 c1 + x1 c0 = a + b - (x0 - x1)(c0 - c1),   x2 c0 = a - (x0 - x2) c0        (a = x0 c0, b = x1 c1)
+// — no operand of x's needs a normalisation.  Outputs as f6_mul_01_t<RX, false>: first and second coefficient un-normalised (limbs
+// within (-2^30, 2^30]), third normalised.
+template <bool RX> GPBC_INLINE F6 f6_mul_01_pn_t(const F6 &x, const F2 &c0, const F2 &c1, const F2 &d01) {
+    F2 a = f2_mul(x.b0, c0), b = f2_mul(x.b1, c1);
+    F2 t0 = f2_add(f2_mul_xi_t<RX>(f2_sub(b, f2_mul(f2_sub(x.b1, x.b2), c1))), a);
+    F2 t1 = f2_sub(f2_add(a, b), f2_mul(f2_sub(x.b0, x.b1), d01));
+    F2 t2 = f2_add(f2_sub(a, f2_mul(f2_sub(x.b0, x.b2), c0)), b);
+    return F6{t0, t1, f2_norm(t2)};
+}
 GPBC_INLINE F6 f6_inv(const F6 &x) {
     F2 t0 = f2_norm(f2_sub(f2_sqr(x.b0), f2_mul_xi_n(f2_mul(x.b1, x.b2))));
     F2 t1 = f2_norm(f2_sub(f2_mul_xi_n(f2_sqr(x.b2)), f2_mul(x.b0, x.b1)));

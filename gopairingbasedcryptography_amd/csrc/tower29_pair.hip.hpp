@@ -80,12 +80,14 @@ template <class X> GPBC_INLINE F6 f12p_one(const X &x) { return f6_sel(x.odd, F6
 template <class X> GPBC_INLINE F6 f12p_conj(const X &x, const F6 &h) { return f6_sel(x.odd, f6_neg(h), h); }
 
 // f^2, complex method: (c0 + c1 w)^2 = (st - m - v m) + 2m w with m = c0 c1, st = (c0 + c1)(c0 + v c1)
-template <class X> GPBC_INLINE F6 f12p_sqr(const X &x, const F6 &h) {
+// PN = true: h is positive-normalised (straight out of fe_norm: the outputs of this function and of the PN sparse products are), and
+// the F6 product takes the subtractive Karatsuba form without operand normalisations (f6_mul_pn_t).
+template <bool PN = false, class X> GPBC_INLINE F6 f12p_sqr(const X &x, const F6 &h) {
     F6 p = x.swap(h);
     // even lane (h = c0, p = c1): m = h * p.   odd lane (h = c1, p = c0): st = (h + p) * (p + v h).
     F6 s = f6_norm(f6_add(h, p));
     F6 t = f6_norm(f6_add(p, f6_mul_v_t<false>(h)));
-    F6 r = f6_mul_t<false>(f6_sel(x.odd, s, h), f6_sel(x.odd, t, p));   // even: m, odd: st
+    F6 r = PN ? f6_mul_pn_t<false>(f6_sel(x.odd, s, h), f6_sel(x.odd, t, p)) : f6_mul_t<false>(f6_sel(x.odd, s, h), f6_sel(x.odd, t, p));   // even: m, odd: st
     F6 pr = x.swap(r);                                                   // even: st, odd: m
     F6 even_out = f6_sub(f6_sub(pr, r), f6_mul_v_t<false>(r));
     F6 odd_out = f6_dbl(pr);
@@ -94,24 +96,28 @@ template <class X> GPBC_INLINE F6 f12p_sqr(const X &x, const F6 &h) {
 
 // f * (l0 + l1 w), l0 = (c0,0,0), l1 = (c3,c4,0):  C0' = a l0 + v (b l1),  C1' = a l1 + b l0.
 // Each lane multiplies its own half by l0 and by l1 (3 + 5 F2 products), then the l1-products are swapped.
-template <class X> GPBC_INLINE F6 f12p_mul_034(const X &x, const F6 &h, const F2 &c0, const F2 &c3, const F2 &c4) {
-    F2 s34 = f2_norm(f2_add(c3, c4));
+// PN = true: h positive-normalised in, positive-normalised out (the value reduction goes in front of the normalisation), and the
+// five-product half in the subtractive form (f6_mul_01_pn_t).
+template <bool PN = false, class X> GPBC_INLINE F6 f12p_mul_034(const X &x, const F6 &h, const F2 &c0, const F2 &c3, const F2 &c4) {
+    F2 s34 = f2_norm(PN ? f2_sub(c3, c4) : f2_add(c3, c4));
     F6 r0 = f6_mul_f2(h, c0);
-    F6 r1 = f6_mul_01_t<false, false>(h, c3, c4, s34);       // b0, b1 un-normalised: they only enter the sum below
+    F6 r1 = PN ? f6_mul_01_pn_t<false>(h, c3, c4, s34) : f6_mul_01_t<false, false>(h, c3, c4, s34);       // b0, b1 un-normalised: they only enter the sum below
     // each lane sends what its partner adds — the odd lane v (b l1), the even lane a l1 — so the received value has one use and
     // rides on the addition (v_add_u32_dpp) instead of costing a move per limb
     F6 send = f6_sel(x.odd, f6_mul_v_t<false>(r1), r1);
-    return f6_reduce_arith(f6_norm(f6p_add_swap(x, r0, send)));          // the one value reduction of this step (no table loads
+    F6 sum = f6p_add_swap(x, r0, send);
+    return PN ? f6_reduce_arith_norm(sum) : f6_reduce_arith(f6_norm(sum));   // the one value reduction of this step (no table loads
                                                                          // here: this runs beside the lines stream, see fe29.hip.hpp)
 }
 
 // f * (1 + l1 w), l1 = (c3, c4, 0) — a line scaled to c0 = 1 (what the fixed-Q line table holds; the scaling factor lies in Fp2
 // and the final exponentiation removes it):  C0' = a + v (b l1),  C1' = b + a l1.  Five F2 products per lane instead of eight.
-template <class X> GPBC_INLINE F6 f12p_mul_34(const X &x, const F6 &h, const F2 &c3, const F2 &c4) {
-    F2 s34 = f2_norm(f2_add(c3, c4));
-    F6 r1 = f6_mul_01_t<false, false>(h, c3, c4, s34);
+template <bool PN = false, class X> GPBC_INLINE F6 f12p_mul_34(const X &x, const F6 &h, const F2 &c3, const F2 &c4) {
+    F2 s34 = f2_norm(PN ? f2_sub(c3, c4) : f2_add(c3, c4));
+    F6 r1 = PN ? f6_mul_01_pn_t<false>(h, c3, c4, s34) : f6_mul_01_t<false, false>(h, c3, c4, s34);
     F6 send = f6_sel(x.odd, f6_mul_v_t<false>(r1), r1);       // as in f12p_mul_034
-    return f6_reduce_arith(f6_norm(f6p_add_swap(x, h, send)));
+    F6 sum = f6p_add_swap(x, h, send);
+    return PN ? f6_reduce_arith_norm(sum) : f6_reduce_arith(f6_norm(sum));
 }
 
 // Product of two lines, (c0 + (c3 + c4 v) w)(d0 + (d3 + d4 v) w), as a lane-pair value:

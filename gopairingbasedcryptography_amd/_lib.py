@@ -28,7 +28,7 @@ EXPORTS = [
     "gpbc_g1_unmarshal_batch_dev", "gpbc_g2_unmarshal_batch_dev", "gpbc_gt_unmarshal_batch_dev",
     "gpbc_g1_map_to_curve_batch", "gpbc_g2_map_to_curve_batch",
     "gpbc_g1_map_to_curve_batch_dev", "gpbc_g2_map_to_curve_batch_dev",
-    "gpbc_set_pipelined_miller", "gpbc_debug_stale_table_once", "gpbc_valu_probe", "gpbc_release_workspaces", "gpbc_hash_to_g1", "gpbc_hash_to_g2", "gpbc_hash_to_field", "gpbc_hash_to_g1_dev", "gpbc_hash_to_g2_dev", "gpbc_hash_to_field_dev",
+    "gpbc_set_pipelined_miller", "gpbc_set_latency_path", "gpbc_debug_stale_table_once", "gpbc_valu_probe", "gpbc_release_workspaces", "gpbc_hash_to_g1", "gpbc_hash_to_g2", "gpbc_hash_to_field", "gpbc_hash_to_g1_dev", "gpbc_hash_to_g2_dev", "gpbc_hash_to_field_dev",
     "gpbc_fixed_base_table_bytes", "gpbc_g1_fixed_base_create", "gpbc_g2_fixed_base_create", "gpbc_fixed_base_create_dev",
     "gpbc_fixed_base_msm", "gpbc_fixed_base_msm_workspace_bytes", "gpbc_fixed_base_msm_dev", "gpbc_fixed_base_destroy",
 ]

@@ -23,7 +23,7 @@ using namespace gpbc;
 // One batch element per lane.  Inputs/outputs are gnark structs (Montgomery R = 2^256, canonical); each kernel
 // converts to the internal 9 x 29-bit signed-limb form on load and back to canonical bytes on store.
 constexpr int BLOCK = 64;
-static_assert(BLOCK == 64, "one wave per workgroup: the LDS slots of the F2 leaf (tower29.hip.hpp) are indexed by the lane number");
+static_assert(BLOCK == 64, "one wave per workgroup: the F6 parking slot (tower29_pair.hip.hpp) is indexed by threadIdx.x < 64; the F2 leaf's argument slots allow 128");
 #define GPBC_WAVES_PER_SIMD 2
 #define GPBC_KERNEL __global__ void __launch_bounds__(BLOCK, GPBC_WAVES_PER_SIMD)
 // G1 arithmetic is light enough on registers for three waves per SIMD (168 VGPRs): measured +12 % over two, while the Fp2 /

@@ -1,6 +1,7 @@
 // libgpbc_bn254.so, unit 2 of 4: Miller loop (two phases, single pairs / shared-squaring chunks / fixed Q), final
 // exponentiation, segment products and the GT kernels, with their C-ABI entries (include/gpbc_bn254.h).  gfx950 only.
 #include "gpbc_common.hpp"
+#include "wide29.hip.hpp"
 #include "pairing29.hip.hpp"
 #include "pairing29_pair.hip.hpp"
 
@@ -280,6 +281,86 @@ GPBC_KERNEL k_miller_accumulate_fixed_q(const int32_t *__restrict__ Pint, const 
     f6_store(f_out + (j * n_c + c) * GPBC_GT_BYTES + (x.odd ? 192 : 0), h);     // segment-major: chunks of a segment are adjacent
 }
 
+// ---- the latency form (csrc/wide29.hip.hpp): ONE pairing per workgroup, Fp12 values as F2 slots in LDS (80 bytes each: 18 limbs +
+// padding, five 128-bit accesses), the lanes working on the F2 products inside the pairing.
+typedef int32_t w128 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ F2 wide_slot_load(const w128 *mem, int slot) {
+    int32_t w[20];
+#pragma unroll
+    for (int c = 0; c < 5; c++) { const w128 t = mem[slot * 5 + c]; w[4 * c] = t.x; w[4 * c + 1] = t.y; w[4 * c + 2] = t.z; w[4 * c + 3] = t.w; }
+    F2 r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) { r.a0.v[i] = w[i]; r.a1.v[i] = w[NL + i]; }
+    return r;
+}
+__device__ __forceinline__ void wide_slot_store(w128 *mem, int slot, const F2 &v) {
+    int32_t w[20];
+#pragma unroll
+    for (int i = 0; i < NL; i++) { w[i] = v.a0.v[i]; w[NL + i] = v.a1.v[i]; }
+    w[18] = 0; w[19] = 0;
+#pragma unroll
+    for (int c = 0; c < 5; c++) mem[slot * 5 + c] = w128{w[4 * c], w[4 * c + 1], w[4 * c + 2], w[4 * c + 3]};
+}
+// The phases of ONE WAVE: its LDS instructions execute in program order, so a phase's stores are visible to the next phase's loads
+// of any lane of the same wave; the fence / wave barrier only keeps the compiler from moving LDS accesses across the phase boundary.
+struct WideLds {
+    w128 *mem;
+    int lane;                                                // lane number inside the wave
+    __device__ __forceinline__ F2 ld(int slot) const { return wide_slot_load(mem, slot); }
+    __device__ __forceinline__ void st(int slot, const F2 &v) const { wide_slot_store(mem, slot, v); }
+    template <class B> __device__ __forceinline__ void run(int n, B &&body) const {
+        if (lane < n) body(lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+};
+// Two waves per pairing: wave 0 walks the G2 point and leaves each of the 88 lines in an LDS ring (21 KB), wave 1 runs the Fp12
+// accumulator and takes line j as soon as the ring's counter says it is there — the two chains (~235 k and ~180 k instructions) run
+// side by side on two SIMDs instead of one after the other.  Both waves belong to one workgroup, so both are resident: the consumer's
+// wait always ends.
+constexpr int WIDE_MILLER_THREADS = 128;
+__global__ void __launch_bounds__(WIDE_MILLER_THREADS, 2) k_miller_wide(const uint8_t *__restrict__ P, const uint8_t *__restrict__ Q, uint8_t *__restrict__ f_out, size_t n) {
+    __shared__ w128 w_mem[W_SLOTS * 5];
+    __shared__ w128 w_ring[MILLER_LINES * 3 * 5];
+    __shared__ int w_lines_ready;
+    const size_t i = blockIdx.x;
+    if (i >= n) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const WideLds m{w_mem, lane};
+    const uint8_t *p = P + i * GPBC_G1_BYTES, *q = Q + i * GPBC_G2_BYTES;
+    if (g1_bytes_inf(p) || g2_bytes_inf(q)) {                // the same for the whole workgroup
+        if (wave == 1 && lane < 6) f2_store(f_out + i * GPBC_GT_BYTES + 64 * lane, f2_sel(lane == 0, f2_one(), f2_zero()));
+        return;
+    }
+    if (threadIdx.x == 0) w_lines_ready = 0;
+    __syncthreads();
+    if (wave == 0) {
+        const G1A a{fe_load(p), fe_load(p + 32)};
+        const G2A b{f2_load(q), f2_load(q + 64)};
+        wide_miller_lines(m, a, b, [&](int j) {
+            m.run(3, [&](int t) { wide_slot_store(w_ring, 3 * j + t, m.ld(W_L0 + t)); });
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __hip_atomic_store(&w_lines_ready, j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        });
+    } else {
+        wide_miller_accumulate(m, wv(0), [&](int j) {
+            while (__hip_atomic_load(&w_lines_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= j) __builtin_amdgcn_s_sleep(2);
+            m.run(3, [&](int t) { m.st(W_CL + t, wide_slot_load(w_ring, 3 * j + t)); });
+        });
+        m.run(6, [&](int k) { f2_store(f_out + i * GPBC_GT_BYTES + 64 * k, m.ld(k)); });
+    }
+}
+GPBC_KERNEL k_final_exp_wide(const uint8_t *f_in, uint8_t *gt_out, size_t n) {
+    __shared__ w128 w_mem[W_SLOTS * 5];
+    const size_t i = blockIdx.x;
+    if (i >= n) return;
+    const WideLds m{w_mem, (int)threadIdx.x};
+    m.run(6, [&](int k) { m.st(k, f2_load(f_in + i * GPBC_GT_BYTES + 64 * k)); });
+    wide_final_exp(m);
+    m.run(6, [&](int k) { f2_store(gt_out + i * GPBC_GT_BYTES + 64 * k, m.ld(k)); });
+}
+
 GPBC_KERNEL k_final_exp(const uint8_t *f_in, uint8_t *gt_out, size_t n) {
     size_t lane = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     size_t i = lane >> 1;
@@ -390,12 +471,27 @@ extern "C" {
 // line missing computes its own: the fallback path, which a healthy run never takes)
 static std::atomic<int> g_pipelined{1};
 int gpbc_set_pipelined_miller(int on) { g_pipelined.store(on == 2 ? 2 : on ? 1 : 0); return GPBC_OK; }
+// Calls of up to this many pairings take the latency form (one pairing per wavefront): up to one wave per SIMD pair of the chip they
+// all run side by side at a lone wave's speed, so the whole call costs one pairing's chain (~2 ms instead of ~6).  0 switches it off.
+constexpr size_t WIDE_DEFAULT_MAX_PAIRS = 2048;
+static std::atomic<size_t> g_wide_max{WIDE_DEFAULT_MAX_PAIRS};
+int gpbc_set_latency_path(long max_pairs) {
+    if (max_pairs < 0) return fail(GPBC_ERR_INVALID_ARG, "max_pairs must be >= 0 (0 = off)");
+    g_wide_max.store((size_t)max_pairs);
+    return GPBC_OK;
+}
 int gpbc_miller_loop_dev(const void *dP, const void *dQ, size_t n, void *d_f_out, void *stream) {
     if (!n) return GPBC_OK;
     if (!dP || !dQ || !d_f_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
     TRY(bind_device());
     hipStream_t st = (hipStream_t)stream;
     size_t chunk = n < MILLER_CHUNK ? n : MILLER_CHUNK;
+    if (n <= g_wide_max.load()) {
+        k_miller_wide<<<(unsigned)n, WIDE_MILLER_THREADS, 0, st>>>((const uint8_t *)dP, (const uint8_t *)dQ, (uint8_t *)d_f_out, n);
+        TRY(check_launch("k_miller_wide"));
+        profile_mark("k_miller_wide", st);
+        return GPBC_OK;
+    }
     if (n <= PIPELINED_MAX_PAIRS && g_pipelined.load()) {
         Scratch flags;                                            // level 2: callers may hold levels 0 and 1 on this stream
         TRY(flags.open(st, 2, n * sizeof(uint32_t)));
@@ -430,6 +526,11 @@ int gpbc_final_exp_dev(const void *d_f, size_t n, void *d_gt_out, void *stream) 
     if (!n) return GPBC_OK;
     if (!d_f || !d_gt_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
     TRY(bind_device());
+    if (n <= g_wide_max.load()) {
+        k_final_exp_wide<<<(unsigned)n, BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_f, (uint8_t *)d_gt_out, n);
+        profile_mark("k_final_exp_wide", (hipStream_t)stream);
+        return check_launch("k_final_exp_wide");
+    }
     k_final_exp<<<grid_for(2 * n), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_f, (uint8_t *)d_gt_out, n);
     profile_mark("k_final_exp", (hipStream_t)stream);
     return check_launch("k_final_exp");

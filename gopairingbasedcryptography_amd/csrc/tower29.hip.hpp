@@ -78,12 +78,13 @@ GPBC_INLINE F2 f2_from_vec(const i32x18 &v) {
 // 20 KB per lane, its dynamic count of scratch stores and loads times four bytes): ten HBM transactions per product, more than
 // half of the kernel's traffic.  They go through LDS instead: a 16-byte and a 4-byte slot per lane of the (64-thread) workgroup,
 // written by the caller right before the call and read first thing by the leaf, in order on the wave's LDS queue.  The slot is
-// addressed by the lane number from v_mbcnt (= threadIdx.x of a one-wave workgroup).
+// addressed by threadIdx.x (the work-item id travels into the leaf in v31).
 // (The stack form measured 57.5 against 55.1 ms on k_miller_accumulate: profiles/r02_variant_lds_args.txt.)
 typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
-__shared__ i32x4 g_f2_arg_slot[64];
-__shared__ int32_t g_f2_arg_slot4[64];
-GPBC_INLINE unsigned f2_arg_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+constexpr int F2_ARG_LANES = 128;               // workgroups have one wave, except the latency form's Miller kernel (two: gpbc_pairing.hip)
+__shared__ i32x4 g_f2_arg_slot[F2_ARG_LANES];
+__shared__ int32_t g_f2_arg_slot4[F2_ARG_LANES];
+GPBC_INLINE unsigned f2_arg_lane() { return threadIdx.x; }
 template <bool NORM> __device__ __noinline__ i32x18 f2_mul_leaf(GPBC_ARGS9(a), GPBC_ARGS9(b), GPBC_ARGS9(c), int32_t d0, int32_t d1, int32_t d2, int32_t d3) {
     const unsigned lane = f2_arg_lane();
     const i32x4 t = g_f2_arg_slot[lane];

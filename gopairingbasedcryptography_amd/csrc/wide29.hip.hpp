@@ -1,0 +1,288 @@
+// LATENCY form of the pairing: ONE pairing per WAVEFRONT, the 64 lanes working on the F2 products INSIDE it.
+//
+// Every reference call site is a single bn254.Pair / PairingCheck.  In the throughput kernels such a call is one
+// lane pair walking a chain of ~2.1 M dependent instructions (accumulator 0.93 M + final exponentiation 1.2 M) while a lone wave
+// issues one instruction every 5-9 cycles: ~5.8 ms whatever the batch size up to a few thousand pairs.  Here the
+// chain is cut by spending lanes: an Fp12 value lives in LDS as six F2 slots, a product of two values is 36 F2 products on 36
+// lanes (schoolbook in the w-basis, w^6 = xi: no operand sums to form) followed by six lanes that add up one output coefficient
+// each; a cyclotomic squaring is nine squarings on nine lanes; the G2 doubling / addition steps are three / four rounds of
+// independent F2 products.  The chain per Fp12 product is one F2 leaf + one recombination (~1.4 k instructions instead of ~8.3 k).
+//
+// Same arithmetic leaves, same tower conventions, same canonical outputs as the throughput path (parity tests compare the two
+// and the oracle); the code is written once over a memory policy M — LDS on the device, an array with interval-carrying values
+// under the host harness (tools/bounds_check.cpp), where the lanes of a phase run one after the other.
+//   M::ld(slot) -> F2        M::st(slot, F2)        M::run(n, body): body(l) for lanes l < n, then a barrier
+#ifndef GPBC_WIDE29_HIP_HPP
+#define GPBC_WIDE29_HIP_HPP
+#include "pairing29.hip.hpp"
+
+namespace gpbc {
+
+// ---- slot map (one F2 per slot).  An Fp12 value is six consecutive slots in tower order C0.b0 C0.b1 C0.b2 C1.b0 C1.b1 C1.b2.
+constexpr int W_VALUES = 12;                         // values 0..11: the accumulator / final-exponentiation registers
+constexpr int W_PROD = 6 * W_VALUES;                 // 36 product slots
+constexpr int W_TX = W_PROD + 36, W_TY = W_TX + 1, W_TZ = W_TX + 2;              // G2 accumulator T (projective)
+constexpr int W_QX = W_TX + 3, W_QY = W_TX + 4, W_NQY = W_TX + 5;                // Q, -Q.y
+constexpr int W_Q1X = W_TX + 6, W_Q1Y = W_TX + 7, W_Q2X = W_TX + 8, W_Q2Y = W_TX + 9;   // pi(Q), -pi^2(Q)
+constexpr int W_XP = W_TX + 10, W_YP = W_TX + 11;                                // P as (xP, 0), (yP, 0)
+constexpr int W_L0 = W_TX + 12, W_L3 = W_TX + 13, W_L4 = W_TX + 14;              // the current line c0, c3, c4
+constexpr int W_G = W_TX + 15;                       // 12 scratch slots of the point steps
+constexpr int W_CL = W_G + 12;                       // the accumulator's copy of the line it is multiplying by (c0, c3, c4)
+constexpr int W_SLOTS = W_CL + 3;
+constexpr int wv(int n) { return 6 * n; }
+GPBC_INLINE int w2t(int k) { return (k >> 1) + 3 * (k & 1); }      // coefficient of w^k -> tower slot offset (0,3,1,4,2,5)
+
+// ---- Fp12 operations on slots
+// dst = a * b.  Schoolbook over the w-basis: c_k = sum_{i+j=k} a_i b_j + xi sum_{i+j=k+6} a_i b_j.
+template <class M> GPBC_INLINE void wide_mul(M &m, int dst, int a, int b) {
+    m.run(36, [&](int l) { const int i = l / 6, j = l % 6; m.st(W_PROD + l, f2_mul(m.ld(a + w2t(i)), m.ld(b + w2t(j)))); });
+    m.run(6, [&](int k) {
+        F2 lo = f2_zero(), hi = f2_zero();
+        for (int i = 0; i < 6; i++) {
+            int j = k - i;
+            const bool is_lo = j >= 0;
+            if (!is_lo) j += 6;
+            const F2 t = m.ld(W_PROD + i * 6 + j);
+            lo = f2_add(lo, f2_sel(is_lo, t, f2_zero()));
+            hi = f2_add(hi, f2_sel(is_lo, f2_zero(), t));
+            if (i == 2) { lo = f2_norm(lo); hi = f2_norm(hi); }      // three products of limbs < 2^29 each, then three more on top of a normalised sum
+        }
+        m.st(dst + w2t(k), f2_reduce(f2_norm(f2_add(f2_norm(lo), f2_mul_xi_nn(f2_norm(hi))))));
+    });
+}
+// dst = a * (c0 + c3 w + c4 w^3): the line of a Miller step (three slots at `line`).  18 products, three terms per coefficient.
+template <class M> GPBC_INLINE void wide_mul_line(M &m, int dst, int a, int line) {
+    m.run(18, [&](int l) { const int i = l / 3, t = l % 3; m.st(W_PROD + l, f2_mul(m.ld(a + w2t(i)), m.ld(line + t))); });
+    m.run(6, [&](int k) {
+        F2 lo = f2_zero(), hi = f2_zero();
+        for (int t = 0; t < 3; t++) {
+            int i = k - (t == 0 ? 0 : t == 1 ? 1 : 3);
+            const bool is_lo = i >= 0;
+            if (!is_lo) i += 6;
+            const F2 p = m.ld(W_PROD + i * 3 + t);
+            lo = f2_add(lo, f2_sel(is_lo, p, f2_zero()));
+            hi = f2_add(hi, f2_sel(is_lo, f2_zero(), p));
+        }
+        m.st(dst + w2t(k), f2_reduce(f2_norm(f2_add(f2_norm(lo), f2_mul_xi_nn(f2_norm(hi))))));
+    });
+}
+// dst = a^2 for a in the cyclotomic subgroup (Granger-Scott; the formulas of f12_cyclo_sqr_t): nine squarings, six outputs.
+template <class M> GPBC_INLINE void wide_cyclo_sqr(M &m, int dst, int a) {
+    m.run(9, [&](int l) {
+        // 0..5: the coefficients themselves; 6: (C0.b0 + C1.b1), 7: (C0.b2 + C1.b0), 8: (C1.b2 + C0.b1)
+        const int u = l < 6 ? l : l == 6 ? 0 : l == 7 ? 2 : 5, v = l < 6 ? l : l == 6 ? 4 : l == 7 ? 3 : 1;
+        const F2 x = m.ld(a + u), y = m.ld(a + v);
+        m.st(W_PROD + l, f2_sqr_n(f2_sel(l < 6, x, f2_add(x, y))));
+    });
+    m.run(6, [&](int k) {
+        const F2 x = m.ld(a + k);
+        F2 out;
+        if (k < 3) {                                         // C0.b_k' = 3 (xi S[A] + S[B]) - 2 x
+            const int A = k == 0 ? 4 : k == 1 ? 2 : 5, B = k == 0 ? 0 : k == 1 ? 3 : 1;
+            const F2 t = f2_norm(f2_add(f2_mul_xi_n(m.ld(W_PROD + A)), m.ld(W_PROD + B)));
+            out = cyclo_out<true>(t, x, false);
+        } else {                                             // C1.b' = 3 [xi] (S[sum] - S[A] - S[B]) + 2 x
+            const int S = k == 3 ? 8 : k == 4 ? 6 : 7, A = k == 3 ? 5 : k == 4 ? 4 : 2, B = k == 3 ? 1 : k == 4 ? 0 : 3;
+            F2 d = f2_sub(f2_sub(m.ld(W_PROD + S), m.ld(W_PROD + A)), m.ld(W_PROD + B));
+            const F2 dx = f2_mul_xi_n(f2_norm(d));
+            d = f2_sel(k == 3, dx, d);
+            out = cyclo_out<true>(d, x, true);
+        }
+        m.st(dst + k, out);
+    });
+}
+template <class M> GPBC_INLINE void wide_copy(M &m, int dst, int a) { m.run(6, [&](int k) { m.st(dst + k, m.ld(a + k)); }); }
+template <class M> GPBC_INLINE void wide_conj(M &m, int dst, int a) {
+    m.run(6, [&](int k) { const F2 x = m.ld(a + k); m.st(dst + k, f2_sel(k >= 3, f2_neg(x), x)); });
+}
+// dst = a^(p^j): coefficient of w^k -> (conjugate if j odd) times gamma_j[k]
+template <class M> GPBC_INLINE void wide_frob(M &m, int dst, int a, int j) {
+    m.run(6, [&](int k) {
+        F2 x = m.ld(a + w2t(k));
+        if (j & 1) x = f2_conj(x);
+        const F2 g = k ? gamma29(j, k) : f2_one();
+        m.st(dst + w2t(k), f2_mul(x, g));
+    });
+}
+// dst = 1 / a: one lane, the single-lane tower (one Fp inversion inside; ~70 k instructions, once per final exponentiation)
+template <class M> GPBC_INLINE void wide_inv(M &m, int dst, int a) {
+    m.run(1, [&](int) {
+        F12 x{F6{m.ld(a), m.ld(a + 1), m.ld(a + 2)}, F6{m.ld(a + 3), m.ld(a + 4), m.ld(a + 5)}};
+        F12 z = f12_inv(x);
+        m.st(dst, z.c0.b0); m.st(dst + 1, z.c0.b1); m.st(dst + 2, z.c0.b2);
+        m.st(dst + 3, f2_norm(z.c1.b0)); m.st(dst + 4, f2_norm(z.c1.b1)); m.st(dst + 5, f2_norm(z.c1.b2));     // (negated products: back to N-class limbs)
+    });
+}
+
+// ---- G2 steps on slots (formulas and names of g2_double_step / g2_add_step; every round is a set of independent F2 products, each
+// lane picking its operand SLOTS by its number — one instruction stream for all of them)
+template <class M> GPBC_INLINE void wide_double_step(M &m) {
+    // round 1: G0 = XY = x y, G1 = B = y^2, G2 = C = z^2, G3 = J = x^2, G4 = YZ = (y + z)^2
+    m.run(5, [&](int l) {
+        const F2 z = m.ld(W_TZ);
+        const F2 a = m.ld(l == 0 || l == 3 ? W_TX : l == 2 ? W_TZ : W_TY), b = m.ld(l == 3 ? W_TX : l == 2 ? W_TZ : W_TY);
+        m.st(W_G + l, f2_mul_nn(f2_sel(l == 4, f2_add(a, z), a), f2_sel(l == 4, f2_add(b, z), b)));
+    });
+    // round 2: G5 = E = 3 C b',  c3 = 3 J xP,  c0 = -H yP with H = YZ - (B + C) (G6 = H normalised)
+    m.run(3, [&](int l) {
+        const F2 H = f2_sub(m.ld(W_G + 4), f2_add(m.ld(W_G + 1), m.ld(W_G + 2)));
+        const F2 v = m.ld(l == 0 ? W_G + 2 : W_G + 3);
+        const F2 lhs = f2_sel(l == 2, f2_norm(f2_neg(H)), f2_norm(f2_add(f2_dbl(v), v)));
+        const F2 rhs = f2_sel(l == 0, b_twist29(), m.ld(l == 1 ? W_XP : W_YP));
+        m.st(l == 0 ? W_G + 5 : l == 1 ? W_L3 : W_L0, f2_mul(lhs, rhs));
+        if (l == 2) m.st(W_G + 6, f2_norm(H));
+    });
+    // round 3: x' = A (B - F), G7 = G^2, G8 = E^2, z' = B H      (A = XY / 2, F = 3 E, G = (B + F) / 2)
+    m.run(4, [&](int l) {
+        const F2 XY = m.ld(W_G), B = m.ld(W_G + 1), E = m.ld(W_G + 5), Hn = m.ld(W_G + 6);
+        const F2 F = f2_add(f2_dbl(E), E);
+        const F2 A = f2_halve(XY), G = f2_halve(f2_norm(f2_add(B, F)));
+        const F2 lhs = f2_sel(l == 0, A, f2_sel(l == 1, G, f2_sel(l == 2, E, B)));
+        const F2 rhs = f2_sel(l == 0, f2_norm(f2_sub(B, F)), f2_sel(l == 1, G, f2_sel(l == 2, E, Hn)));
+        m.st(l == 0 ? W_TX : l == 1 ? W_G + 7 : l == 2 ? W_G + 8 : W_TZ, f2_mul_nn(lhs, rhs));
+    });
+    // linear: y' = G^2 - 3 E^2,  c4 = E - B
+    m.run(2, [&](int l) {
+        const F2 EE = m.ld(W_G + 8);
+        const F2 y = f2_sub(m.ld(W_G + 7), f2_add(f2_dbl(EE), EE)), c4 = f2_sub(m.ld(W_G + 5), m.ld(W_G + 1));
+        m.st(l == 0 ? W_TY : W_L4, f2_norm(f2_sel(l == 0, y, c4)));
+    });
+}
+// T <- T + Q' and the chord (Q' = slots qx, qy); with_point = false: the chord alone (last step of the loop)
+template <class M> GPBC_INLINE void wide_add_step(M &m, int qx, int qy, bool with_point) {
+    // round 1: G0 = O = y - qy z,  G1 = L = x - qx z
+    m.run(2, [&](int l) {
+        const F2 p = f2_mul(m.ld(l == 0 ? qy : qx), m.ld(W_TZ));
+        m.st(W_G + l, f2_norm(f2_sub(m.ld(l == 0 ? W_TY : W_TX), p)));
+    });
+    // round 2: G2 = C = O^2, G3 = D = L^2, G4 = M1 = O qx, G5 = M2 = L qy, c0 = L yP, c3 = -O xP
+    m.run(6, [&](int l) {
+        const F2 a = m.ld(l == 0 || l == 2 || l == 5 ? W_G : W_G + 1);
+        const F2 b = m.ld(l == 0 ? W_G : l == 1 ? W_G + 1 : l == 2 ? qx : l == 3 ? qy : l == 4 ? W_YP : W_XP);
+        m.st(l < 4 ? W_G + 2 + l : l == 4 ? W_L0 : W_L3, f2_mul(f2_sel(l == 5, f2_norm(f2_neg(a)), a), b));
+    });
+    if (!with_point) {
+        m.run(1, [&](int) { m.st(W_L4, f2_norm(f2_sub(m.ld(W_G + 4), m.ld(W_G + 5)))); });
+        return;
+    }
+    // round 3: G6 = E = L D, G7 = F = z C, G8 = G = x D
+    m.run(3, [&](int l) { m.st(W_G + 6 + l, f2_mul(m.ld(l == 0 ? W_G + 1 : l == 1 ? W_TZ : W_TX), m.ld(l == 1 ? W_G + 2 : W_G + 3))); });
+    // round 4: G9 = x' = L H, G10 = U = (G - H) O, G11 = t1 = y E, G2 = z' = E z       (H = E + F - 2 G)
+    m.run(4, [&](int l) {
+        const F2 E = m.ld(W_G + 6), F = m.ld(W_G + 7), G = m.ld(W_G + 8);
+        const F2 H = f2_norm(f2_sub(f2_add(E, F), f2_dbl(G)));
+        const F2 a = m.ld(l == 0 ? W_G + 1 : l == 2 ? W_TY : W_G + 6), b = m.ld(l == 1 ? W_G : l == 2 ? W_G + 6 : W_TZ);
+        m.st(l == 3 ? W_G + 2 : W_G + 9 + l, f2_mul(f2_sel(l == 1, f2_norm(f2_sub(G, H)), a), f2_sel(l == 0, H, b)));
+    });
+    // linear: T <- (x', U - t1, z'),  c4 = M1 - M2
+    m.run(4, [&](int l) {
+        const F2 a = m.ld(l == 0 ? W_G + 9 : l == 1 ? W_G + 10 : l == 2 ? W_G + 2 : W_G + 4), b = m.ld(l == 1 ? W_G + 11 : W_G + 5);
+        m.st(l == 0 ? W_TX : l == 1 ? W_TY : l == 2 ? W_TZ : W_L4, f2_sel(l == 1 || l == 3, f2_norm(f2_sub(a, b)), a));
+    });
+}
+
+// ---- the Miller loop in two halves that share nothing but the 88 lines: the G2 walk (producer: slots W_TX .. W_G) and the
+// accumulator (consumer: the value slots, W_PROD, W_CL).  On the device they run as two waves of one workgroup, the lines passing
+// through an LDS ring (gpbc_pairing.hip: k_miller_wide); under the host harness one after the other.  P, Q not at infinity.
+//   emit(j): line j is in W_L0, W_L3, W_L4          fetch(j): put line j into W_CL .. W_CL + 2
+template <class M, class Emit> GPBC_INLINE void wide_miller_lines(M &m, const G1A &p, const G2A &q, Emit &&emit) {
+    m.run(1, [&](int) {
+        m.st(W_TX, q.x); m.st(W_TY, q.y); m.st(W_TZ, f2_one());
+        m.st(W_QX, q.x); m.st(W_QY, q.y); m.st(W_NQY, f2_neg(q.y));
+        m.st(W_Q1X, f2_mul(f2_conj(q.x), gamma29(1, 2))); m.st(W_Q1Y, f2_mul(f2_conj(q.y), gamma29(1, 3)));
+        m.st(W_Q2X, f2_mul(q.x, gamma29(2, 2))); m.st(W_Q2Y, f2_norm(f2_neg(f2_mul(q.y, gamma29(2, 3)))));
+        m.st(W_XP, F2{p.x, fe_zero()}); m.st(W_YP, F2{p.y, fe_zero()});
+    });
+    int j = 0;
+    for (int i = BN254_ATE_NAF_LEN - 2; i >= 0; i--) {
+        wide_double_step(m);
+        emit(j++);
+        const int d = ate_naf_digit(i);
+        if (d != 0) {
+            wide_add_step(m, W_QX, d > 0 ? W_QY : W_NQY, true);
+            emit(j++);
+        }
+    }
+    wide_add_step(m, W_Q1X, W_Q1Y, true);
+    emit(j++);
+    wide_add_step(m, W_Q2X, W_Q2Y, false);
+    emit(j++);
+}
+template <class M, class Fetch> GPBC_INLINE void wide_miller_accumulate(M &m, int f, Fetch &&fetch) {
+    int j = 0;
+    for (int i = BN254_ATE_NAF_LEN - 2; i >= 0; i--) {
+        fetch(j++);
+        if (i == BN254_ATE_NAF_LEN - 2) {
+            // the first doubling: f = 1^2 * l = c0 + c3 w + c4 w^3
+            m.run(6, [&](int k) { m.st(f + k, f2_sel(k == 0 || k == 3 || k == 4, m.ld(k == 0 ? W_CL : k == 3 ? W_CL + 1 : W_CL + 2), f2_zero())); });
+        } else {
+            wide_mul(m, f, f, f);
+            wide_mul_line(m, f, f, W_CL);
+        }
+        if (ate_naf_digit(i) != 0) {
+            fetch(j++);
+            wide_mul_line(m, f, f, W_CL);
+        }
+    }
+    for (int k = 0; k < 2; k++) {
+        fetch(j++);
+        wide_mul_line(m, f, f, W_CL);
+    }
+}
+
+// ---- final exponentiation (operation order of final_exp29 / final_exp_pair)
+template <class M> GPBC_INLINE void wide_cyclo_sqr_n(M &m, int v, int n) { for (int i = 0; i < n; i++) wide_cyclo_sqr(m, v, v); }
+// z = x^u, width-4 signed windows; tab = four consecutive values, tmp = one value
+template <class M> GPBC_INLINE void wide_expt(M &m, int z, int x, int tab, int tmp) {
+    constexpr int8_t D[GPBC_U_WNAF4_LEN] = GPBC_U_WNAF4;
+    wide_copy(m, tab, x);
+    wide_cyclo_sqr(m, tmp, x);
+    for (int k = 1; k < 4; k++) wide_mul(m, tab + 6 * k, tab + 6 * (k - 1), tmp);
+    wide_copy(m, z, tab + 6 * ((D[GPBC_U_WNAF4_LEN - 1] - 1) / 2));
+    int run = 0;
+    for (int i = GPBC_U_WNAF4_LEN - 2; i >= 0; i--) {
+        run++;
+        const int d = D[i];
+        if (d != 0) {
+            wide_cyclo_sqr_n(m, z, run);
+            run = 0;
+            const int e = tab + 6 * (((d < 0 ? -d : d) - 1) / 2);
+            if (d < 0) { wide_conj(m, tmp, e); wide_mul(m, z, z, tmp); }
+            else wide_mul(m, z, z, e);
+        }
+    }
+    if (run) wide_cyclo_sqr_n(m, z, run);
+}
+// value slot `f` <- f^(s (p^12 - 1) / r); uses values 1..11 as registers (f must be value 0)
+template <class M> GPBC_INLINE void wide_final_exp(M &m) {
+    constexpr int F = wv(0), R = wv(1), T0 = wv(2), T1 = wv(3), T2 = wv(4), T3 = wv(5), T4 = wv(6), TAB = wv(7), TMP = wv(11);
+    wide_inv(m, T1, F);
+    wide_conj(m, T0, F);
+    wide_mul(m, T0, T0, T1);
+    wide_frob(m, R, T0, 2);
+    wide_mul(m, R, R, T0);
+    wide_expt(m, T0, R, TAB, TMP); wide_conj(m, T0, T0);
+    wide_cyclo_sqr(m, T0, T0);
+    wide_cyclo_sqr(m, T1, T0);
+    wide_mul(m, T1, T0, T1);
+    wide_expt(m, T2, T1, TAB, TMP); wide_conj(m, T2, T2);
+    wide_conj(m, T3, T1);
+    wide_mul(m, T1, T2, T3);
+    wide_cyclo_sqr(m, T3, T2);
+    wide_expt(m, T4, T3, TAB, TMP);
+    wide_mul(m, T4, T1, T4);
+    wide_mul(m, T3, T0, T4);
+    wide_mul(m, T0, T2, T4);
+    wide_mul(m, T0, R, T0);
+    wide_frob(m, T2, T3, 1);
+    wide_mul(m, T0, T2, T0);
+    wide_frob(m, T2, T4, 2);
+    wide_mul(m, T0, T2, T0);
+    wide_conj(m, T2, R);
+    wide_mul(m, T2, T2, T3);
+    wide_frob(m, T2, T2, 3);
+    wide_mul(m, F, T2, T0);
+}
+
+}  // namespace gpbc
+#endif

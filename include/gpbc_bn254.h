@@ -139,6 +139,13 @@ int gpbc_set_multi_pair_chunk(int pairs_per_chunk);
  * large batches (tests compare the two); default 1.  2 = pipelined with no waiting at all (a consumer that finds its line
  * missing computes its own lines: the bounded-wait fallback, for tests). */
 int gpbc_set_pipelined_miller(int on);
+/* The LATENCY path.  Every reference call site is ONE bn254.Pair / PairingCheck (cpabe/bsw07/bsw07_cpabe.go:184,
+ * signature/bls01_signature/bls_signature.go:81, ...); in the throughput kernels one pairing is a chain of ~2 M dependent
+ * instructions on one lane pair — ~6 ms per call whatever the batch size.  Calls of at most `max_pairs` Miller loops / final
+ * exponentiations (default 2048: one wave per SIMD pair of the chip) run ONE PAIRING PER WAVEFRONT instead, the 64 lanes working
+ * on the F2 products inside it (csrc/wide29.hip.hpp): same bits, about a third of the latency.  0 switches the path off (tests
+ * compare the two forms). */
+int gpbc_set_latency_path(long max_pairs);
 /* Fail-closed self-check of the host-table multi-pairings (gpbc_multi_pair, gpbc_pairing_check, gpbc_multi_pair_hostseg_dev): the
  * segment / chunk tables travel through library-owned pinned memory, the kernels echo the pairs they consumed per segment, and
  * the call returns GPBC_ERR_INTERNAL with zeroed outputs unless the echo equals the caller's table — a product over fewer pairs

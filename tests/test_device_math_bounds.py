@@ -303,3 +303,26 @@ def test_executed_mad_counts_file_is_current(hc):
         assert abs(got[unit] - want) <= 1, (unit, got[unit], want)
     # the device does 81 limb products where SURVEY's nominal CIOS has 64, and lazy Fp2 products: more MADs than nominal for the pairing
     assert doc["mads_per_unit"]["pairing"] > doc["nominal_mac_per_unit"]["pairing"]
+
+
+def test_wide_latency_form_under_bounds(hc, oracle):
+    """csrc/wide29.hip.hpp: one pairing per wavefront, Fp12 values as F2 slots in LDS, the lanes of a wave working on the F2 products
+    inside ONE pairing (the latency path of Pair / PairingCheck).  The host harness runs the lanes of every phase one after the
+    other on interval-carrying slots: Miller value (through the oracle's final exponentiation) and the full pairing must match the
+    oracle bit for bit, a point at infinity gives one, and no int64 column / int32 limb can overflow for any input."""
+    n = 3
+    g1 = np.frombuffer(o.g1_to_bytes(o.G1_GEN), dtype=np.uint8)
+    g2 = np.frombuffer(o.g2_to_bytes(o.G2_GEN), dtype=np.uint8)
+    k = np.frombuffer(b"".join(o.scalar_to_bytes(o.bench_scalar("wide", 7 + i)) for i in range(n)), dtype=np.uint8).copy()
+    P, Q = oracle.g1_scalar_mul(g1, k), oracle.g2_scalar_mul(g2, k)
+    P = np.ascontiguousarray(P); Q = np.ascontiguousarray(Q)
+    ref = oracle.pair_batch(P, Q)
+    f = np.zeros((n, 384), dtype=np.uint8)
+    hc.hc_pair_wide(vp(P), vp(Q), ctypes.c_size_t(n), vp(f), ctypes.c_int(0))
+    assert (oracle.final_exp(f) == ref).all()
+    gt = np.zeros((n, 384), dtype=np.uint8)
+    hc.hc_pair_wide(vp(P), vp(Q), ctypes.c_size_t(n), vp(gt), ctypes.c_int(1))
+    assert (gt == ref).all()
+    P0 = P.copy(); P0[1] = 0
+    hc.hc_pair_wide(vp(P0), vp(Q), ctypes.c_size_t(n), vp(gt), ctypes.c_int(1))
+    assert (gt == oracle.pair_batch(P0, Q)).all()

@@ -179,6 +179,43 @@ def test_pipelined_small_batches_match_the_two_kernel_form(eng, oracle):
     assert e1[5].tobytes() == o.gt_to_bytes(o.F12_ONE) and e1[64].tobytes() == o.gt_to_bytes(o.F12_ONE)
 
 
+def test_latency_path_matches_the_throughput_kernels(eng, oracle):
+    """Calls of up to 2 048 pairings take the latency form (csrc/wide29.hip.hpp: one pairing per wavefront, the Miller loop as two waves
+    passing lines through an LDS ring, Fp12 values as F2 slots in LDS).  Same bytes as the throughput kernels
+    (gpbc_set_latency_path(0)) and as the oracle: Miller values, full pairings, PairingCheck and ragged multi-pairings, sizes around
+    the switch-over, points at infinity, host and device buffers."""
+    import torch
+    from gopairingbasedcryptography_amd import _lib
+    lib = _lib.load()
+    g1, g2 = eng.generators()
+    n = 2100
+    P = eng.g1_scalar_mul(g1, scalars("wide-P", n))
+    Q = eng.g2_scalar_mul(g2, scalars("wide-Q", n))
+    P[3] = 0
+    Q[70] = 0
+    dP, dQ = torch.from_numpy(P).cuda(), torch.from_numpy(Q).cuda()
+    seg = np.array([0, 2, 2, 5, 9, 10], dtype=np.uint64)
+    nP = P[:10].copy(); nP[1] = eng.g1_neg(P[0]); nQ = Q[:10].copy(); nQ[1] = Q[0]        # segment 0: e(P,Q) e(-P,Q) = 1
+    try:
+        for m in (1, 2, 3, 64, 65, 700, 2048, n):
+            _lib.check(lib.gpbc_set_latency_path(0))
+            f0, e0 = eng.miller_loop(P[:m], Q[:m]), eng.pair_batch(P[:m], Q[:m])
+            _lib.check(lib.gpbc_set_latency_path(2048))
+            f1, e1 = eng.miller_loop(P[:m], Q[:m]), eng.pair_batch(dP[:m].contiguous(), dQ[:m].contiguous()).cpu().numpy()
+            # Miller values are defined up to factors the final exponentiation removes: compare them through it
+            assert (eng.final_exp(f1) == e0).all() and (e1 == e0).all(), m
+        for knob in (0, 2048):
+            _lib.check(lib.gpbc_set_latency_path(knob))
+            mp = eng.multi_pair(nP, nQ, seg)
+            ok = eng.pairing_check_batch(nP, nQ, seg)
+            assert (mp == oracle.multi_pair(nP, nQ, seg)).all(), knob
+            assert list(ok) == [True, True, False, False, False], knob
+    finally:
+        lib.gpbc_set_latency_path(2048)
+    assert (e1[:64] == oracle.pair_batch(P[:64], Q[:64], threads=8)).all()
+    assert e1[3].tobytes() == o.gt_to_bytes(o.F12_ONE) and e1[70].tobytes() == o.gt_to_bytes(o.F12_ONE)
+
+
 def test_multi_pair_fixed_q(eng, oracle, synth):
     """One shared G2 list against k segments of G1 points (precomputed lines): equal to multi_pair on the replicated list
     and to the oracle, for forced chunk lengths and the automatic one; infinities on both sides; device path."""

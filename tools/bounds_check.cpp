@@ -11,6 +11,7 @@
 #include "../gopairingbasedcryptography_amd/csrc/curve29.hip.hpp"
 #include "../gopairingbasedcryptography_amd/csrc/pairing29.hip.hpp"
 #include "../gopairingbasedcryptography_amd/csrc/pairing29_pair.hip.hpp"
+#include "../gopairingbasedcryptography_amd/csrc/wide29.hip.hpp"
 #include "../gopairingbasedcryptography_amd/csrc/wire29.hip.hpp"
 #include "../gopairingbasedcryptography_amd/csrc/h2c29.hip.hpp"
 #include "../gopairingbasedcryptography_amd/csrc/msm29.hip.hpp"
@@ -102,8 +103,39 @@ template <class F, class LoadA, class StoreA> static void msm_host(const uint8_t
     AffP<F> a; jac_to_affine(a, acc);
     st(out, a);
 }
+// host memory policy of the latency ("wide") form, csrc/wide29.hip.hpp: the slots are interval-carrying values, the lanes of a
+// phase run one after the other and their stores land when the phase ends (what the barrier does on the device)
+struct WideHost {
+    std::vector<F2> s = std::vector<F2>(W_SLOTS, f2_zero());
+    std::vector<std::pair<int, F2>> pending;
+    F2 ld(int i) const { return s[i]; }
+    void st(int i, const F2 &v) { pending.emplace_back(i, v); }
+    template <class B> void run(int n, B &&body) {
+        for (int l = 0; l < n; l++) body(l);
+        for (auto &p : pending) s[p.first] = p.second;
+        pending.clear();
+    }
+};
 extern "C" {
 
+// one pairing per "wavefront": Miller loop and final exponentiation of the latency form (k_miller_wide / k_final_exp_wide)
+void hc_pair_wide(const uint8_t *P, const uint8_t *Q, size_t n, uint8_t *out, int do_final_exp) {
+    for (size_t i = 0; i < n; i++) {
+        const uint8_t *p = P + 64 * i, *q = Q + 128 * i;
+        WideHost m;
+        if (bytes_all_zero(p, 16) || bytes_all_zero(q, 32)) { m.s[0] = f2_one(); }
+        else {
+            G1A a{fe_load(p), fe_load(p + 32)};
+            G2A b{f2_load(q), f2_load(q + 64)};
+            std::vector<F2> ring;                          // the device passes the 88 lines through an LDS ring, wave to wave
+            wide_miller_lines(m, a, b, [&](int) { m.run(3, [&](int t) { ring.push_back(m.ld(W_L0 + t)); }); });
+            wide_miller_accumulate(m, wv(0), [&](int j) { m.run(3, [&](int t) { m.st(W_CL + t, ring[3 * j + t]); }); });
+        }
+        if (do_final_exp) wide_final_exp(m);
+        for (int k = 0; k < 6; k++) f2_store(out + 384 * i + 64 * k, m.s[k]);
+        stats_flush();
+    }
+}
 void hc_pair(const uint8_t *P, const uint8_t *Q, size_t n, uint8_t *out) {
     for (size_t i = 0; i < n; i++) {
         const uint8_t *p = P + 64 * i, *q = Q + 128 * i;

@@ -74,21 +74,21 @@ template <class M> GPBC_INLINE void wide_cyclo_sqr(M &m, int dst, int a) {
         const F2 x = m.ld(a + u), y = m.ld(a + v);
         m.st(W_PROD + l, f2_sqr_n(f2_sel(l < 6, x, f2_add(x, y))));
     });
+    // six outputs, ONE instruction stream (a per-lane branch would run both forms one after the other):
+    //   k < 3:  C0.b_k' = 3 (xi S[A] + S[B]) - 2 x          k >= 3:  C1.b' = 3 [xi] (S[sum] - S[A] - S[B]) + 2 x   (xi for k = 3 only)
     m.run(6, [&](int k) {
+        const bool c0 = k < 3;
+        const int S = k == 3 ? 8 : k == 4 ? 6 : 7;
+        const int A = k == 0 ? 4 : k == 1 ? 2 : k == 2 ? 5 : k == 3 ? 5 : k == 4 ? 4 : 2;
+        const int B = k == 0 ? 0 : k == 1 ? 3 : k == 2 ? 1 : k == 3 ? 1 : k == 4 ? 0 : 3;
+        const F2 sA = m.ld(W_PROD + A), sB = m.ld(W_PROD + B);
+        const F2 d = f2_sub(f2_sub(m.ld(W_PROD + S), sA), sB);                 // (k >= 3)
+        const F2 X = f2_mul_xi_nn(f2_sel(c0, sA, f2_norm(d)));                 // xi S[A]  |  xi (cross term)
+        const F2 t = f2_sel(c0, f2_norm(f2_add(X, sB)), f2_sel(k == 3, X, d));
+        // 3 t -+ 2 x with the value reduction at the end (cyclo_out with the sign as a per-lane select)
         const F2 x = m.ld(a + k);
-        F2 out;
-        if (k < 3) {                                         // C0.b_k' = 3 (xi S[A] + S[B]) - 2 x
-            const int A = k == 0 ? 4 : k == 1 ? 2 : 5, B = k == 0 ? 0 : k == 1 ? 3 : 1;
-            const F2 t = f2_norm(f2_add(f2_mul_xi_n(m.ld(W_PROD + A)), m.ld(W_PROD + B)));
-            out = cyclo_out<true>(t, x, false);
-        } else {                                             // C1.b' = 3 [xi] (S[sum] - S[A] - S[B]) + 2 x
-            const int S = k == 3 ? 8 : k == 4 ? 6 : 7, A = k == 3 ? 5 : k == 4 ? 4 : 2, B = k == 3 ? 1 : k == 4 ? 0 : 3;
-            F2 d = f2_sub(f2_sub(m.ld(W_PROD + S), m.ld(W_PROD + A)), m.ld(W_PROD + B));
-            const F2 dx = f2_mul_xi_n(f2_norm(d));
-            d = f2_sel(k == 3, dx, d);
-            out = cyclo_out<true>(d, x, true);
-        }
-        m.st(dst + k, out);
+        const F2 dd = f2_norm(f2_add(t, f2_sel(c0, f2_neg(x), x)));
+        m.st(dst + k, f2_reduce(f2_norm(f2_add(f2_dbl(dd), t))));
     });
 }
 template <class M> GPBC_INLINE void wide_copy(M &m, int dst, int a) { m.run(6, [&](int k) { m.st(dst + k, m.ld(a + k)); }); }
@@ -104,14 +104,19 @@ template <class M> GPBC_INLINE void wide_frob(M &m, int dst, int a, int j) {
         m.st(dst + w2t(k), f2_mul(x, g));
     });
 }
-// dst = 1 / a: one lane, the single-lane tower (one Fp inversion inside; ~70 k instructions, once per final exponentiation)
-template <class M> GPBC_INLINE void wide_inv(M &m, int dst, int a) {
+// dst = 1 / a = conj(a) / (a conj(a)): the norm N = a conj(a) lies in Fp6 (its C1 half is zero), so one wide product, ONE lane for the
+// Fp6 inversion (nine F2 products and one Fp inversion: ~25 k instructions, where a whole single-lane Fp12 inversion is ~70 k) and a
+// second wide product.  tmp: one value of scratch.
+template <class M> GPBC_INLINE void wide_inv(M &m, int dst, int a, int tmp) {
+    wide_conj(m, tmp, a);
+    wide_mul(m, dst, a, tmp);                                // N = (c0^2 - v c1^2, 0)
     m.run(1, [&](int) {
-        F12 x{F6{m.ld(a), m.ld(a + 1), m.ld(a + 2)}, F6{m.ld(a + 3), m.ld(a + 4), m.ld(a + 5)}};
-        F12 z = f12_inv(x);
-        m.st(dst, z.c0.b0); m.st(dst + 1, z.c0.b1); m.st(dst + 2, z.c0.b2);
-        m.st(dst + 3, f2_norm(z.c1.b0)); m.st(dst + 4, f2_norm(z.c1.b1)); m.st(dst + 5, f2_norm(z.c1.b2));     // (negated products: back to N-class limbs)
+        const F6 n{m.ld(dst), m.ld(dst + 1), m.ld(dst + 2)};
+        const F6 z = f6_inv(n);
+        m.st(dst, z.b0); m.st(dst + 1, z.b1); m.st(dst + 2, z.b2);
+        m.st(dst + 3, f2_zero()); m.st(dst + 4, f2_zero()); m.st(dst + 5, f2_zero());
     });
+    wide_mul(m, dst, dst, tmp);
 }
 
 // ---- G2 steps on slots (formulas and names of g2_double_step / g2_add_step; every round is a set of independent F2 products, each
@@ -256,8 +261,7 @@ template <class M> GPBC_INLINE void wide_expt(M &m, int z, int x, int tab, int t
 // value slot `f` <- f^(s (p^12 - 1) / r); uses values 1..11 as registers (f must be value 0)
 template <class M> GPBC_INLINE void wide_final_exp(M &m) {
     constexpr int F = wv(0), R = wv(1), T0 = wv(2), T1 = wv(3), T2 = wv(4), T3 = wv(5), T4 = wv(6), TAB = wv(7), TMP = wv(11);
-    wide_inv(m, T1, F);
-    wide_conj(m, T0, F);
+    wide_inv(m, T1, F, T0);                                  // (T0 = conj(f) on the way out)
     wide_mul(m, T0, T0, T1);
     wide_frob(m, R, T0, 2);
     wide_mul(m, R, R, T0);

@@ -249,7 +249,8 @@ int gpbc_gt_marshal_batch_dev(const void *d_gt, size_t n, void *d_out, void *str
  * form is read from the flag bits (a compressed encoding in the first half of a 64/128-byte slot is accepted, an
  * uncompressed flag in a 32/64-byte slot is a short buffer).  ok_out[i] = 1 where gnark returns no error and 0 where it
  * returns one — coordinate >= p, malformed infinity, no square root, point not on the curve / not in the order-r
- * subgroup (G2: [r]Q != infinity) — and then the output element is all zero.  The reference ignores that error
+ * subgroup (G2: decided, as gnark does, by the endomorphism identity [x+1]Q + psi([x]Q) + psi^2([x]Q) = psi^3([2x]Q), which holds
+ * exactly on the points with [r]Q = infinity; tests/test_wire.py compares the two) — and then the output element is all zero.  The reference ignores that error
  * (serialization_curve.go:19,25,31); callers of this entry should not.  Not in place. */
 int gpbc_g1_unmarshal_batch(const void *in, size_t elem_bytes, size_t n, void *pts_out, uint8_t *ok_out);
 int gpbc_g2_unmarshal_batch(const void *in, size_t elem_bytes, size_t n, void *pts_out, uint8_t *ok_out);

@@ -361,6 +361,29 @@ GPBC_KERNEL k_final_exp_wide(const uint8_t *f_in, uint8_t *gt_out, size_t n) {
     m.run(6, [&](int k) { f2_store(gt_out + i * GPBC_GT_BYTES + 64 * k, m.ld(k)); });
 }
 
+// The product of a segment's Miller values and its final exponentiation in one launch, one segment per wavefront: what
+// k_segment_product (one lane, serial Fp12 products) + k_final_exp_wide do for the small calls of the latency path.  Same clamping
+// of the table and the same echo (first value, values consumed) as k_segment_product.
+GPBC_KERNEL k_segment_final_exp_wide(const uint8_t *__restrict__ f, const uint64_t *__restrict__ seg_off, uint8_t *__restrict__ out, size_t k, size_t n_vals,
+                                     uint64_t *__restrict__ echo) {
+    __shared__ w128 w_mem[W_SLOTS * 5];
+    const size_t j = blockIdx.x;
+    if (j >= k) return;
+    const WideLds m{w_mem, (int)threadIdx.x};
+    uint64_t lo = seg_off[j], hi = seg_off[j + 1];
+    if (hi > n_vals) hi = n_vals;
+    if (lo > hi) lo = hi;
+    if (lo == hi) m.run(6, [&](int c) { m.st(c, f2_sel(c == 0, f2_one(), f2_zero())); });
+    else m.run(6, [&](int c) { m.st(c, f2_load(f + lo * GPBC_GT_BYTES + 64 * c)); });
+    for (uint64_t i = lo + 1; i < hi; i++) {
+        m.run(6, [&](int c) { m.st(wv(1) + c, f2_load(f + i * GPBC_GT_BYTES + 64 * c)); });
+        wide_mul(m, wv(0), wv(0), wv(1));
+    }
+    wide_final_exp(m);
+    m.run(6, [&](int c) { f2_store(out + j * GPBC_GT_BYTES + 64 * c, m.ld(c)); });
+    if (echo && threadIdx.x == 0) { echo[2 * j] = lo; echo[2 * j + 1] = hi - lo; }
+}
+
 GPBC_KERNEL k_final_exp(const uint8_t *f_in, uint8_t *gt_out, size_t n) {
     size_t lane = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     size_t i = lane >> 1;
@@ -547,6 +570,12 @@ static int multi_pair_dev_echo(const void *dP, const void *dQ, const uint64_t *d
     if (!d_seg_off || !d_gt_out || (n_pairs && (!dP || !dQ || !d_workspace))) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
     if (workspace_bytes < gpbc_multi_pair_workspace_bytes(n_pairs, k)) return fail(GPBC_ERR_WORKSPACE, "workspace too small");
     TRY(gpbc_miller_loop_dev(dP, dQ, n_pairs, d_workspace, stream));
+    if (k <= g_wide_max.load() && n_pairs <= g_wide_max.load()) {              // the latency path: product and exponentiation per wavefront
+        k_segment_final_exp_wide<<<(unsigned)k, BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_workspace, d_seg_off, (uint8_t *)d_gt_out, k, n_pairs, d_echo);
+        TRY(check_launch("k_segment_final_exp_wide"));
+        profile_mark("k_segment_final_exp_wide", (hipStream_t)stream);
+        return GPBC_OK;
+    }
     k_segment_product<<<grid_for(k), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_workspace, d_seg_off, (uint8_t *)d_gt_out, k, n_pairs, nullptr, d_echo);
     TRY(check_launch("k_segment_product"));
     profile_mark("k_segment_product", (hipStream_t)stream);

@@ -98,10 +98,11 @@ int main() {
     {
         G2Affine hm = HashStandIn("hello pairing"), inv, forged_inv; inv.Neg(sig);
         G2Affine forged = Sign(b.sk, "hello pairing"); forged_inv.Neg(forged);       // b's signature offered under a's key
-        struct Mode { const char *name; int chunk, pipelined; };
-        const Mode modes[] = {{"general", 0, 1}, {"two-kernel Miller loop", 0, 0}, {"pipelined without waiting", 0, 2}, {"chunks of 2", 2, 1}, {"chunks of 1", 1, 1}};
+        struct Mode { const char *name; int chunk, pipelined; long latency; };
+        const Mode modes[] = {{"latency form (one pairing per wavefront)", 0, 1, 2048}, {"throughput kernels, pipelined Miller loop", 0, 1, 0},
+                              {"two-kernel Miller loop", 0, 0, 0}, {"pipelined without waiting", 0, 2, 0}, {"chunks of 2", 2, 1, 0}, {"chunks of 1", 1, 1, 2048}};
         for (const Mode &m : modes) {
-            check(gpbc_set_multi_pair_chunk(m.chunk)); check(gpbc_set_pipelined_miller(m.pipelined));
+            check(gpbc_set_multi_pair_chunk(m.chunk)); check(gpbc_set_pipelined_miller(m.pipelined)); check(gpbc_set_latency_path(m.latency));
             for (int rep = 0; rep < 3; rep++) {
                 EXPECT(Verify(a.pk, "hello pairing", sig));
                 EXPECT(!PairingCheck({a.pk, g1}, {hm, forged_inv}));
@@ -127,7 +128,7 @@ int main() {
             EXPECT(!PairingCheck({a.pk, g1}, {hm, forged_inv}) && Verify(a.pk, "hello pairing", sig));   // and the next calls are sound
             printf("  multi-pairing path '%s': accepts, rejects, fails closed on a stale table\n", m.name);
         }
-        check(gpbc_set_multi_pair_chunk(0)); check(gpbc_set_pipelined_miller(1));
+        check(gpbc_set_multi_pair_chunk(0)); check(gpbc_set_pipelined_miller(1)); check(gpbc_set_latency_path(2048));
     }
     printf("BLS flow OK\n");
     return 0;

@@ -166,6 +166,7 @@ def test_pipelined_small_batches_match_the_two_kernel_form(eng, oracle):
     P[n - 1] = 0
     dP, dQ = torch.from_numpy(P).cuda(), torch.from_numpy(Q).cuda()
     try:
+        _lib.check(lib.gpbc_set_latency_path(0))           # the latency form would take every call of up to 2 048 pairs (it has its own test)
         for m in (1, 2, 31, 32, 33, 63, 64, 65, 1000, 16384, n):
             _lib.check(lib.gpbc_set_pipelined_miller(0))
             f0, e0 = eng.miller_loop(P[:m], Q[:m]), eng.pair_batch(P[:m], Q[:m])
@@ -175,6 +176,7 @@ def test_pipelined_small_batches_match_the_two_kernel_form(eng, oracle):
                 assert (f1 == f0).all() and (e1 == e0).all(), (m, mode)
     finally:
         lib.gpbc_set_pipelined_miller(1)
+        lib.gpbc_set_latency_path(2048)
     assert (e1[:200] == oracle.pair_batch(P[:200], Q[:200], threads=8)).all()
     assert e1[5].tobytes() == o.gt_to_bytes(o.F12_ONE) and e1[64].tobytes() == o.gt_to_bytes(o.F12_ONE)
 
@@ -210,10 +212,17 @@ def test_latency_path_matches_the_throughput_kernels(eng, oracle):
             ok = eng.pairing_check_batch(nP, nQ, seg)
             assert (mp == oracle.multi_pair(nP, nQ, seg)).all(), knob
             assert list(ok) == [True, True, False, False, False], knob
+            # one long segment (the product of 300 Miller values: a serial chain of wide products in the latency form), an empty one, a single
+            long_seg = np.array([0, 300, 300, 301], dtype=np.uint64)
+            got = eng.multi_pair(P[:301], Q[:301], long_seg)
+            if knob == 0:
+                want_long = got
+            assert (got == want_long).all(), knob
     finally:
         lib.gpbc_set_latency_path(2048)
     assert (e1[:64] == oracle.pair_batch(P[:64], Q[:64], threads=8)).all()
     assert e1[3].tobytes() == o.gt_to_bytes(o.F12_ONE) and e1[70].tobytes() == o.gt_to_bytes(o.F12_ONE)
+    assert (want_long == oracle.multi_pair(P[:301], Q[:301], long_seg, threads=8)).all()
 
 
 def test_multi_pair_fixed_q(eng, oracle, synth):
@@ -766,6 +775,18 @@ def test_hash_to_field_on_device(eng):
         eng.hash_to_field(np.frombuffer(b"abc", dtype=np.uint8), b"d", 2, msg_off=np.array([0, 5], dtype=np.uint64))
     with pytest.raises(ValueError):
         eng.hash_to_field([b"abc"], b"d", 3)
+    # an empty DST passed as NULL / 0 through the raw C ABI (what the Go shim does: unsafe.SliceData of an empty slice may be nil)
+    import ctypes
+    from gopairingbasedcryptography_amd import _lib
+    lib = _lib.load()
+    data = np.frombuffer(b"abcdef", dtype=np.uint8).copy()
+    offs = np.array([0, 3, 6], dtype=np.uint64)
+    out = np.zeros((2, 64), dtype=np.uint8)
+    _lib.check(lib.gpbc_hash_to_g1(data.ctypes.data_as(ctypes.c_void_p), offs.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(2), None, ctypes.c_size_t(0),
+                                   out.ctypes.data_as(ctypes.c_void_p)))
+    assert (out == eng.hash_to_g1([b"abc", b"def"], b"")).all()
+    assert lib.gpbc_hash_to_g1(data.ctypes.data_as(ctypes.c_void_p), offs.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(2), None, ctypes.c_size_t(5),
+                               out.ctypes.data_as(ctypes.c_void_p)) < 0          # NULL with a length is an error, not a crash
     for fn in (eng.hash_to_g1, eng.hash_to_g2, eng.hash_to_field):      # gnark's ExpandMsgXmd: "invalid domain size" above 255 bytes; the
         with pytest.raises(ValueError):                                 # Go shim answers the same (gpbcbn254.go), and so does this front end
             fn([b"abc"], b"R" * 256)

@@ -281,26 +281,23 @@ GPBC_KERNEL k_miller_accumulate_fixed_q(const int32_t *__restrict__ Pint, const 
     f6_store(f_out + (j * n_c + c) * GPBC_GT_BYTES + (x.odd ? 192 : 0), h);     // segment-major: chunks of a segment are adjacent
 }
 
-// ---- the latency form (csrc/wide29.hip.hpp): ONE pairing per workgroup, Fp12 values as F2 slots in LDS (80 bytes each: 18 limbs +
-// padding, five 128-bit accesses), the lanes working on the F2 products inside the pairing.
+// ---- the latency form (csrc/wide29.hip.hpp): ONE pairing per workgroup, Fp12 values as F2 slots in LDS (96 bytes each), the lanes
+// working on the F2 products inside the pairing.
 typedef int32_t w128 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ F2 wide_slot_load(const w128 *mem, int slot) {
-    int32_t w[20];
-#pragma unroll
-    for (int c = 0; c < 5; c++) { const w128 t = mem[slot * 5 + c]; w[4 * c] = t.x; w[4 * c + 1] = t.y; w[4 * c + 2] = t.z; w[4 * c + 3] = t.w; }
-    F2 r;
-#pragma unroll
-    for (int i = 0; i < NL; i++) { r.a0.v[i] = w[i]; r.a1.v[i] = w[NL + i]; }
+// one slot = 96 bytes: a0 in three 128-bit words (nine limbs + padding), a1 in the next three — either half can be read or written alone
+__device__ __forceinline__ Fe wide_half_load(const w128 *mem, int slot, int h) {
+    const w128 t0 = mem[slot * 6 + 3 * h], t1 = mem[slot * 6 + 3 * h + 1], t2 = mem[slot * 6 + 3 * h + 2];
+    Fe r;
+    r.v[0] = t0.x; r.v[1] = t0.y; r.v[2] = t0.z; r.v[3] = t0.w; r.v[4] = t1.x; r.v[5] = t1.y; r.v[6] = t1.z; r.v[7] = t1.w; r.v[8] = t2.x;
     return r;
 }
-__device__ __forceinline__ void wide_slot_store(w128 *mem, int slot, const F2 &v) {
-    int32_t w[20];
-#pragma unroll
-    for (int i = 0; i < NL; i++) { w[i] = v.a0.v[i]; w[NL + i] = v.a1.v[i]; }
-    w[18] = 0; w[19] = 0;
-#pragma unroll
-    for (int c = 0; c < 5; c++) mem[slot * 5 + c] = w128{w[4 * c], w[4 * c + 1], w[4 * c + 2], w[4 * c + 3]};
+__device__ __forceinline__ void wide_half_store(w128 *mem, int slot, int h, const Fe &v) {
+    mem[slot * 6 + 3 * h] = w128{v.v[0], v.v[1], v.v[2], v.v[3]};
+    mem[slot * 6 + 3 * h + 1] = w128{v.v[4], v.v[5], v.v[6], v.v[7]};
+    mem[slot * 6 + 3 * h + 2] = w128{v.v[8], 0, 0, 0};
 }
+__device__ __forceinline__ F2 wide_slot_load(const w128 *mem, int slot) { return F2{wide_half_load(mem, slot, 0), wide_half_load(mem, slot, 1)}; }
+__device__ __forceinline__ void wide_slot_store(w128 *mem, int slot, const F2 &v) { wide_half_store(mem, slot, 0, v.a0); wide_half_store(mem, slot, 1, v.a1); }
 // The phases of ONE WAVE: its LDS instructions execute in program order, so a phase's stores are visible to the next phase's loads
 // of any lane of the same wave; the fence / wave barrier only keeps the compiler from moving LDS accesses across the phase boundary.
 struct WideLds {
@@ -308,6 +305,8 @@ struct WideLds {
     int lane;                                                // lane number inside the wave
     __device__ __forceinline__ F2 ld(int slot) const { return wide_slot_load(mem, slot); }
     __device__ __forceinline__ void st(int slot, const F2 &v) const { wide_slot_store(mem, slot, v); }
+    __device__ __forceinline__ Fe ldh(int slot, int h) const { return wide_half_load(mem, slot, h); }
+    __device__ __forceinline__ void sth(int slot, int h, const Fe &v) const { wide_half_store(mem, slot, h, v); }
     template <class B> __device__ __forceinline__ void run(int n, B &&body) const {
         if (lane < n) body(lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -321,8 +320,8 @@ struct WideLds {
 // wait always ends.
 constexpr int WIDE_MILLER_THREADS = 128;
 __global__ void __launch_bounds__(WIDE_MILLER_THREADS, 2) k_miller_wide(const uint8_t *__restrict__ P, const uint8_t *__restrict__ Q, uint8_t *__restrict__ f_out, size_t n) {
-    __shared__ w128 w_mem[W_SLOTS * 5];
-    __shared__ w128 w_ring[MILLER_LINES * 3 * 5];
+    __shared__ w128 w_mem[W_SLOTS * 6];
+    __shared__ w128 w_ring[MILLER_LINES * 3 * 6];
     __shared__ int w_lines_ready;
     const size_t i = blockIdx.x;
     if (i >= n) return;
@@ -352,7 +351,7 @@ __global__ void __launch_bounds__(WIDE_MILLER_THREADS, 2) k_miller_wide(const ui
     }
 }
 GPBC_KERNEL k_final_exp_wide(const uint8_t *f_in, uint8_t *gt_out, size_t n) {
-    __shared__ w128 w_mem[W_SLOTS * 5];
+    __shared__ w128 w_mem[W_SLOTS * 6];
     const size_t i = blockIdx.x;
     if (i >= n) return;
     const WideLds m{w_mem, (int)threadIdx.x};
@@ -366,7 +365,7 @@ GPBC_KERNEL k_final_exp_wide(const uint8_t *f_in, uint8_t *gt_out, size_t n) {
 // of the table and the same echo (first value, values consumed) as k_segment_product.
 GPBC_KERNEL k_segment_final_exp_wide(const uint8_t *__restrict__ f, const uint64_t *__restrict__ seg_off, uint8_t *__restrict__ out, size_t k, size_t n_vals,
                                      uint64_t *__restrict__ echo) {
-    __shared__ w128 w_mem[W_SLOTS * 5];
+    __shared__ w128 w_mem[W_SLOTS * 6];
     const size_t j = blockIdx.x;
     if (j >= k) return;
     const WideLds m{w_mem, (int)threadIdx.x};

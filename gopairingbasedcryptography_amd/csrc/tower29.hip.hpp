@@ -97,6 +97,21 @@ template <bool NORM> GPBC_INLINE F2 f2_mul_call(const F2 &x, const F2 &y) {
     g_f2_arg_slot4[lane] = y.a1.v[4];
     return f2_from_vec(f2_mul_leaf<NORM>(GPBC_PASS9(x.a0), GPBC_PASS9(x.a1), GPBC_PASS9(y.a0), y.a1.v[0], y.a1.v[1], y.a1.v[2], y.a1.v[3]));
 }
+// a b + c d in one reduction, as a leaf of its own with the same LDS argument slots (36 operand limbs again): one HALF of an F2 product.
+// The latency form (wide29.hip.hpp) gives the two halves of every F2 product to two lanes.
+__device__ __noinline__ Fe fe_mul2_lds_leaf(GPBC_ARGS9(a), GPBC_ARGS9(b), GPBC_ARGS9(c), int32_t d0, int32_t d1, int32_t d2, int32_t d3) {
+    const unsigned lane = f2_arg_lane();
+    const i32x4 t = g_f2_arg_slot[lane];
+    const int32_t d4 = g_f2_arg_slot4[lane], d5 = t.x, d6 = t.y, d7 = t.z, d8 = t.w;
+    Fe a = GPBC_PACK9(a), b = GPBC_PACK9(b), c = GPBC_PACK9(c), d = GPBC_PACK9(d);
+    return fe_mul_core<true>(a, b, c, d);
+}
+GPBC_INLINE Fe fe_mul2_l(const Fe &a, const Fe &b, const Fe &c, const Fe &d) {
+    const unsigned lane = f2_arg_lane();
+    g_f2_arg_slot[lane] = i32x4{d.v[5], d.v[6], d.v[7], d.v[8]};
+    g_f2_arg_slot4[lane] = d.v[4];
+    return fe_mul2_lds_leaf(GPBC_PASS9(a), GPBC_PASS9(b), GPBC_PASS9(c), d.v[0], d.v[1], d.v[2], d.v[3]);
+}
 template <bool NORM> __device__ __noinline__ i32x18 f2_sqr_leaf(GPBC_ARGS9(a), GPBC_ARGS9(b)) {
     return f2_to_vec(f2_sqr_core<NORM>(GPBC_PACK_F2(a, b)));
 }
@@ -105,6 +120,7 @@ GPBC_INLINE F2 f2_mul_nn(const F2 &x, const F2 &y) { return f2_mul_call<true>(x,
 GPBC_INLINE F2 f2_sqr(const F2 &x) { return f2_from_vec(f2_sqr_leaf<false>(GPBC_PASS9(x.a0), GPBC_PASS9(x.a1))); }
 GPBC_INLINE F2 f2_sqr_n(const F2 &x) { return f2_from_vec(f2_sqr_leaf<true>(GPBC_PASS9(x.a0), GPBC_PASS9(x.a1))); }
 #else
+GPBC_INLINE Fe fe_mul2_l(const Fe &a, const Fe &b, const Fe &c, const Fe &d) { return fe_mul_core<true>(a, b, c, d); }
 GPBC_INLINE F2 f2_mul(const F2 &x, const F2 &y) { return f2_mul_core<false>(x, y); }
 GPBC_INLINE F2 f2_mul_nn(const F2 &x, const F2 &y) { return f2_mul_core<true>(x, y); }      // both operands un-normalised sums
 GPBC_INLINE F2 f2_sqr(const F2 &x) { return f2_sqr_core<false>(x); }

@@ -12,6 +12,10 @@
 // and the oracle); the code is written once over a memory policy M — LDS on the device, an array with interval-carrying values
 // under the host harness (tools/bounds_check.cpp), where the lanes of a phase run one after the other.
 //   M::ld(slot) -> F2        M::st(slot, F2)        M::run(n, body): body(l) for lanes l < n, then a barrier
+//   M::ldh(slot, half) -> Fe    M::sth(slot, half, Fe): one half (0: a0, 1: a1) of a slot
+// A lone wave issues one v_mad_i64_i32 per ~9 cycles, so wherever the lanes are there the two HALVES of an F2 product go to two lanes
+// (r0 = a0 b0 - a1 b1, r1 = a0 b1 + a1 b0: one 243-MAD leaf each instead of one 486-MAD leaf), and the recombinations run per Fp
+// component as well: sums on 24 lanes, the xi step and the reduction on 12.
 #ifndef GPBC_WIDE29_HIP_HPP
 #define GPBC_WIDE29_HIP_HPP
 #include "pairing29.hip.hpp"
@@ -28,67 +32,104 @@ constexpr int W_XP = W_TX + 10, W_YP = W_TX + 11;                               
 constexpr int W_L0 = W_TX + 12, W_L3 = W_TX + 13, W_L4 = W_TX + 14;              // the current line c0, c3, c4
 constexpr int W_G = W_TX + 15;                       // 12 scratch slots of the point steps
 constexpr int W_CL = W_G + 12;                       // the accumulator's copy of the line it is multiplying by (c0, c3, c4)
-constexpr int W_SLOTS = W_CL + 3;
+constexpr int W_LO = W_CL + 3, W_HI = W_LO + 6;      // partial sums of a recombination: un-wrapped and wrapped (times xi) terms per coefficient
+constexpr int W_SLOTS = W_HI + 6;
 constexpr int wv(int n) { return 6 * n; }
 GPBC_INLINE int w2t(int k) { return (k >> 1) + 3 * (k & 1); }      // coefficient of w^k -> tower slot offset (0,3,1,4,2,5)
 
+// ---- half products: lane (product p, half h) of a product phase
+// h = 0: a0 b0 - a1 b1      h = 1: a0 b1 + a1 b0          (a, b N-class)
+GPBC_INLINE Fe wide_half_mul(const F2 &a, const F2 &b, bool h) {
+    return fe_mul2_l(a.a0, fe_sel(h, b.a1, b.a0), fe_sel(h, a.a1, fe_neg(a.a1)), fe_sel(h, b.a0, b.a1));
+}
+// h = 0: (x0 + x1)(x0 - x1)      h = 1: (2 x0) x1          (x normalised: a single Fp product takes one operand with limbs up to 2^30)
+GPBC_INLINE Fe wide_half_sqr(const F2 &x, bool h) {
+    return fe_mul(fe_sel(h, fe_dbl(x.a0), fe_add(x.a0, x.a1)), fe_sel(h, x.a1, fe_sub(x.a0, x.a1)));
+}
+// one component of (9 + i)(m + o i) seen from the lane that holds `mine`: 9 a0 - a1 (h = 0) or 9 a1 + a0 (h = 1); not normalised
+GPBC_INLINE Fe wide_xi_half(const Fe &mine, const Fe &other, bool h) {
+    return fe_add(fe_add(fe_mul8_norm(mine), mine), fe_sel(h, other, fe_neg(other)));
+}
+// Recombination of product halves into the six coefficients of dst, in two phases:
+//   24 lanes (coefficient k, lo / hi, half): the sum of the terms of that kind, term(k, t) -> product slot and whether it wraps
+//   (i + j >= 6: multiplied by xi), normalised after every third term;
+//   12 lanes (k, half): lo + xi hi, normalised and value-reduced.
+template <class M, class Term> GPBC_INLINE void wide_recombine(M &m, int dst, int n_terms, Term &&term) {
+    m.run(24, [&](int L) {
+        const int k = L >> 2, h = L & 1;
+        const bool want_hi = (L & 2) != 0;
+        Fe acc = fe_zero();
+        for (int t = 0; t < n_terms; t++) {
+            int slot;
+            bool wraps;
+            term(k, t, slot, wraps);
+            acc = fe_add(acc, fe_sel(wraps == want_hi, m.ldh(slot, h), fe_zero()));
+            if (t % 3 == 2) acc = fe_norm(acc);
+        }
+        m.sth((want_hi ? W_HI : W_LO) + k, h, fe_norm(acc));
+    });
+    m.run(12, [&](int L) {
+        const int k = L >> 1;
+        const bool h = L & 1;
+        const F2 hi = m.ld(W_HI + k);
+        const Fe x = fe_norm(wide_xi_half(h ? hi.a1 : hi.a0, h ? hi.a0 : hi.a1, h));
+        m.sth(dst + w2t(k), h, fe_reduce(fe_norm(fe_add(m.ldh(W_LO + k, h), x))));
+    });
+}
+
 // ---- Fp12 operations on slots
-// dst = a * b.  Schoolbook over the w-basis: c_k = sum_{i+j=k} a_i b_j + xi sum_{i+j=k+6} a_i b_j.
+// dst = a * b.  Schoolbook over the w-basis: c_k = sum_{i+j=k} a_i b_j + xi sum_{i+j=k+6} a_i b_j.  (36 products: 72 halves would
+// need a second wave, so this one keeps whole F2 products on 36 lanes.)
 template <class M> GPBC_INLINE void wide_mul(M &m, int dst, int a, int b) {
     m.run(36, [&](int l) { const int i = l / 6, j = l % 6; m.st(W_PROD + l, f2_mul(m.ld(a + w2t(i)), m.ld(b + w2t(j)))); });
-    m.run(6, [&](int k) {
-        F2 lo = f2_zero(), hi = f2_zero();
-        for (int i = 0; i < 6; i++) {
-            int j = k - i;
-            const bool is_lo = j >= 0;
-            if (!is_lo) j += 6;
-            const F2 t = m.ld(W_PROD + i * 6 + j);
-            lo = f2_add(lo, f2_sel(is_lo, t, f2_zero()));
-            hi = f2_add(hi, f2_sel(is_lo, f2_zero(), t));
-            if (i == 2) { lo = f2_norm(lo); hi = f2_norm(hi); }      // three products of limbs < 2^29 each, then three more on top of a normalised sum
-        }
-        m.st(dst + w2t(k), f2_reduce(f2_norm(f2_add(f2_norm(lo), f2_mul_xi_nn(f2_norm(hi))))));
+    wide_recombine(m, dst, 6, [](int k, int i, int &slot, bool &wraps) {
+        int j = k - i;
+        wraps = j < 0;
+        if (wraps) j += 6;
+        slot = W_PROD + i * 6 + j;
     });
 }
-// dst = a * (c0 + c3 w + c4 w^3): the line of a Miller step (three slots at `line`).  18 products, three terms per coefficient.
+// dst = a * (c0 + c3 w + c4 w^3): the line of a Miller step (three slots at `line`).  18 products as 36 halves, three terms per coefficient.
 template <class M> GPBC_INLINE void wide_mul_line(M &m, int dst, int a, int line) {
-    m.run(18, [&](int l) { const int i = l / 3, t = l % 3; m.st(W_PROD + l, f2_mul(m.ld(a + w2t(i)), m.ld(line + t))); });
-    m.run(6, [&](int k) {
-        F2 lo = f2_zero(), hi = f2_zero();
-        for (int t = 0; t < 3; t++) {
-            int i = k - (t == 0 ? 0 : t == 1 ? 1 : 3);
-            const bool is_lo = i >= 0;
-            if (!is_lo) i += 6;
-            const F2 p = m.ld(W_PROD + i * 3 + t);
-            lo = f2_add(lo, f2_sel(is_lo, p, f2_zero()));
-            hi = f2_add(hi, f2_sel(is_lo, f2_zero(), p));
-        }
-        m.st(dst + w2t(k), f2_reduce(f2_norm(f2_add(f2_norm(lo), f2_mul_xi_nn(f2_norm(hi))))));
+    m.run(36, [&](int L) {
+        const int l = L >> 1, i = l / 3, t = l % 3;
+        m.sth(W_PROD + l, L & 1, wide_half_mul(m.ld(a + w2t(i)), m.ld(line + t), L & 1));
+    });
+    wide_recombine(m, dst, 3, [](int k, int t, int &slot, bool &wraps) {
+        int i = k - (t == 0 ? 0 : t == 1 ? 1 : 3);
+        wraps = i < 0;
+        if (wraps) i += 6;
+        slot = W_PROD + i * 3 + t;
     });
 }
-// dst = a^2 for a in the cyclotomic subgroup (Granger-Scott; the formulas of f12_cyclo_sqr_t): nine squarings, six outputs.
+// dst = a^2 for a in the cyclotomic subgroup (Granger-Scott; the formulas of f12_cyclo_sqr_t): nine squarings as 18 halves, six
+// outputs as 12.
 template <class M> GPBC_INLINE void wide_cyclo_sqr(M &m, int dst, int a) {
-    m.run(9, [&](int l) {
-        // 0..5: the coefficients themselves; 6: (C0.b0 + C1.b1), 7: (C0.b2 + C1.b0), 8: (C1.b2 + C0.b1)
+    m.run(18, [&](int L) {
+        // squarings 0..5: the coefficients themselves; 6: (C0.b0 + C1.b1), 7: (C0.b2 + C1.b0), 8: (C1.b2 + C0.b1)
+        const int l = L >> 1;
         const int u = l < 6 ? l : l == 6 ? 0 : l == 7 ? 2 : 5, v = l < 6 ? l : l == 6 ? 4 : l == 7 ? 3 : 1;
         const F2 x = m.ld(a + u), y = m.ld(a + v);
-        m.st(W_PROD + l, f2_sqr_n(f2_sel(l < 6, x, f2_add(x, y))));
+        m.sth(W_PROD + l, L & 1, wide_half_sqr(f2_norm(f2_sel(l < 6, x, f2_add(x, y))), L & 1));
     });
-    // six outputs, ONE instruction stream (a per-lane branch would run both forms one after the other):
+    // twelve output halves, ONE instruction stream (a per-lane branch would run both forms one after the other):
     //   k < 3:  C0.b_k' = 3 (xi S[A] + S[B]) - 2 x          k >= 3:  C1.b' = 3 [xi] (S[sum] - S[A] - S[B]) + 2 x   (xi for k = 3 only)
-    m.run(6, [&](int k) {
-        const bool c0 = k < 3;
+    m.run(12, [&](int L) {
+        const int k = L >> 1;
+        const bool h = L & 1, c0 = k < 3;
         const int S = k == 3 ? 8 : k == 4 ? 6 : 7;
         const int A = k == 0 ? 4 : k == 1 ? 2 : k == 2 ? 5 : k == 3 ? 5 : k == 4 ? 4 : 2;
         const int B = k == 0 ? 0 : k == 1 ? 3 : k == 2 ? 1 : k == 3 ? 1 : k == 4 ? 0 : 3;
         const F2 sA = m.ld(W_PROD + A), sB = m.ld(W_PROD + B);
-        const F2 d = f2_sub(f2_sub(m.ld(W_PROD + S), sA), sB);                 // (k >= 3)
-        const F2 X = f2_mul_xi_nn(f2_sel(c0, sA, f2_norm(d)));                 // xi S[A]  |  xi (cross term)
-        const F2 t = f2_sel(c0, f2_norm(f2_add(X, sB)), f2_sel(k == 3, X, d));
-        // 3 t -+ 2 x with the value reduction at the end (cyclo_out with the sign as a per-lane select)
-        const F2 x = m.ld(a + k);
-        const F2 dd = f2_norm(f2_add(t, f2_sel(c0, f2_neg(x), x)));
-        m.st(dst + k, f2_reduce(f2_norm(f2_add(f2_dbl(dd), t))));
+        const F2 d = f2_norm(f2_sub(f2_sub(m.ld(W_PROD + S), sA), sB));           // (k >= 3; both halves: the xi step mixes them)
+        const F2 U = f2_sel(c0, sA, d);
+        const Fe X = fe_norm(wide_xi_half(h ? U.a1 : U.a0, h ? U.a0 : U.a1, h));  // xi S[A]  |  xi (cross term)
+        const Fe sBm = h ? sB.a1 : sB.a0, dm = h ? d.a1 : d.a0;
+        const Fe t = fe_sel(c0, fe_norm(fe_add(X, sBm)), fe_sel(k == 3, X, dm));
+        // 3 t -+ 2 x with the value reduction at the end
+        const Fe x = m.ldh(a + k, h);
+        const Fe dd = fe_norm(fe_add(t, fe_sel(c0, fe_neg(x), x)));
+        m.sth(dst + k, h, fe_reduce(fe_norm(fe_add(fe_dbl(dd), t))));
     });
 }
 template <class M> GPBC_INLINE void wide_copy(M &m, int dst, int a) { m.run(6, [&](int k) { m.st(dst + k, m.ld(a + k)); }); }
@@ -97,11 +138,12 @@ template <class M> GPBC_INLINE void wide_conj(M &m, int dst, int a) {
 }
 // dst = a^(p^j): coefficient of w^k -> (conjugate if j odd) times gamma_j[k]
 template <class M> GPBC_INLINE void wide_frob(M &m, int dst, int a, int j) {
-    m.run(6, [&](int k) {
+    m.run(12, [&](int L) {
+        const int k = L >> 1;
         F2 x = m.ld(a + w2t(k));
         if (j & 1) x = f2_conj(x);
         const F2 g = k ? gamma29(j, k) : f2_one();
-        m.st(dst + w2t(k), f2_mul(x, g));
+        m.sth(dst + w2t(k), L & 1, wide_half_mul(x, g, L & 1));
     });
 }
 // dst = 1 / a = conj(a) / (a conj(a)): the norm N = a conj(a) lies in Fp6 (its C1 half is zero), so one wide product, ONE lane for the
@@ -123,66 +165,77 @@ template <class M> GPBC_INLINE void wide_inv(M &m, int dst, int a, int tmp) {
 // lane picking its operand SLOTS by its number — one instruction stream for all of them)
 template <class M> GPBC_INLINE void wide_double_step(M &m) {
     // round 1: G0 = XY = x y, G1 = B = y^2, G2 = C = z^2, G3 = J = x^2, G4 = YZ = (y + z)^2
-    m.run(5, [&](int l) {
+    m.run(10, [&](int L) {
+        const int l = L >> 1;
         const F2 z = m.ld(W_TZ);
         const F2 a = m.ld(l == 0 || l == 3 ? W_TX : l == 2 ? W_TZ : W_TY), b = m.ld(l == 3 ? W_TX : l == 2 ? W_TZ : W_TY);
-        m.st(W_G + l, f2_mul_nn(f2_sel(l == 4, f2_add(a, z), a), f2_sel(l == 4, f2_add(b, z), b)));
+        m.sth(W_G + l, L & 1, wide_half_mul(f2_norm(f2_sel(l == 4, f2_add(a, z), a)), f2_norm(f2_sel(l == 4, f2_add(b, z), b)), L & 1));
     });
     // round 2: G5 = E = 3 C b',  c3 = 3 J xP,  c0 = -H yP with H = YZ - (B + C) (G6 = H normalised)
-    m.run(3, [&](int l) {
+    m.run(6, [&](int L) {
+        const int l = L >> 1;
         const F2 H = f2_sub(m.ld(W_G + 4), f2_add(m.ld(W_G + 1), m.ld(W_G + 2)));
         const F2 v = m.ld(l == 0 ? W_G + 2 : W_G + 3);
         const F2 lhs = f2_sel(l == 2, f2_norm(f2_neg(H)), f2_norm(f2_add(f2_dbl(v), v)));
         const F2 rhs = f2_sel(l == 0, b_twist29(), m.ld(l == 1 ? W_XP : W_YP));
-        m.st(l == 0 ? W_G + 5 : l == 1 ? W_L3 : W_L0, f2_mul(lhs, rhs));
-        if (l == 2) m.st(W_G + 6, f2_norm(H));
+        m.sth(l == 0 ? W_G + 5 : l == 1 ? W_L3 : W_L0, L & 1, wide_half_mul(lhs, rhs, L & 1));
+        if (l == 2) m.sth(W_G + 6, L & 1, fe_norm((L & 1) ? H.a1 : H.a0));
     });
     // round 3: x' = A (B - F), G7 = G^2, G8 = E^2, z' = B H      (A = XY / 2, F = 3 E, G = (B + F) / 2)
-    m.run(4, [&](int l) {
+    m.run(8, [&](int L) {
+        const int l = L >> 1;
         const F2 XY = m.ld(W_G), B = m.ld(W_G + 1), E = m.ld(W_G + 5), Hn = m.ld(W_G + 6);
         const F2 F = f2_add(f2_dbl(E), E);
-        const F2 A = f2_halve(XY), G = f2_halve(f2_norm(f2_add(B, F)));
-        const F2 lhs = f2_sel(l == 0, A, f2_sel(l == 1, G, f2_sel(l == 2, E, B)));
+        const F2 A = f2_halve(XY), G = f2_norm(f2_halve(f2_norm(f2_add(B, F))));
+        const F2 lhs = f2_sel(l == 0, f2_norm(A), f2_sel(l == 1, G, f2_sel(l == 2, E, B)));
         const F2 rhs = f2_sel(l == 0, f2_norm(f2_sub(B, F)), f2_sel(l == 1, G, f2_sel(l == 2, E, Hn)));
-        m.st(l == 0 ? W_TX : l == 1 ? W_G + 7 : l == 2 ? W_G + 8 : W_TZ, f2_mul_nn(lhs, rhs));
+        m.sth(l == 0 ? W_TX : l == 1 ? W_G + 7 : l == 2 ? W_G + 8 : W_TZ, L & 1, wide_half_mul(lhs, rhs, L & 1));
     });
     // linear: y' = G^2 - 3 E^2,  c4 = E - B
-    m.run(2, [&](int l) {
-        const F2 EE = m.ld(W_G + 8);
-        const F2 y = f2_sub(m.ld(W_G + 7), f2_add(f2_dbl(EE), EE)), c4 = f2_sub(m.ld(W_G + 5), m.ld(W_G + 1));
-        m.st(l == 0 ? W_TY : W_L4, f2_norm(f2_sel(l == 0, y, c4)));
+    m.run(4, [&](int L) {
+        const int l = L >> 1, h = L & 1;
+        const Fe EE = m.ldh(W_G + 8, h);
+        const Fe y = fe_sub(m.ldh(W_G + 7, h), fe_add(fe_dbl(EE), EE)), c4 = fe_sub(m.ldh(W_G + 5, h), m.ldh(W_G + 1, h));
+        m.sth(l == 0 ? W_TY : W_L4, h, fe_norm(fe_sel(l == 0, y, c4)));
     });
 }
 // T <- T + Q' and the chord (Q' = slots qx, qy); with_point = false: the chord alone (last step of the loop)
 template <class M> GPBC_INLINE void wide_add_step(M &m, int qx, int qy, bool with_point) {
     // round 1: G0 = O = y - qy z,  G1 = L = x - qx z
-    m.run(2, [&](int l) {
-        const F2 p = f2_mul(m.ld(l == 0 ? qy : qx), m.ld(W_TZ));
-        m.st(W_G + l, f2_norm(f2_sub(m.ld(l == 0 ? W_TY : W_TX), p)));
+    m.run(4, [&](int L) {
+        const int l = L >> 1, h = L & 1;
+        const Fe p = wide_half_mul(m.ld(l == 0 ? qy : qx), m.ld(W_TZ), h);
+        m.sth(W_G + l, h, fe_norm(fe_sub(m.ldh(l == 0 ? W_TY : W_TX, h), p)));
     });
     // round 2: G2 = C = O^2, G3 = D = L^2, G4 = M1 = O qx, G5 = M2 = L qy, c0 = L yP, c3 = -O xP
-    m.run(6, [&](int l) {
+    m.run(12, [&](int L) {
+        const int l = L >> 1;
         const F2 a = m.ld(l == 0 || l == 2 || l == 5 ? W_G : W_G + 1);
         const F2 b = m.ld(l == 0 ? W_G : l == 1 ? W_G + 1 : l == 2 ? qx : l == 3 ? qy : l == 4 ? W_YP : W_XP);
-        m.st(l < 4 ? W_G + 2 + l : l == 4 ? W_L0 : W_L3, f2_mul(f2_sel(l == 5, f2_norm(f2_neg(a)), a), b));
+        m.sth(l < 4 ? W_G + 2 + l : l == 4 ? W_L0 : W_L3, L & 1, wide_half_mul(f2_sel(l == 5, f2_norm(f2_neg(a)), a), b, L & 1));
     });
     if (!with_point) {
-        m.run(1, [&](int) { m.st(W_L4, f2_norm(f2_sub(m.ld(W_G + 4), m.ld(W_G + 5)))); });
+        m.run(2, [&](int h) { m.sth(W_L4, h, fe_norm(fe_sub(m.ldh(W_G + 4, h), m.ldh(W_G + 5, h)))); });
         return;
     }
     // round 3: G6 = E = L D, G7 = F = z C, G8 = G = x D
-    m.run(3, [&](int l) { m.st(W_G + 6 + l, f2_mul(m.ld(l == 0 ? W_G + 1 : l == 1 ? W_TZ : W_TX), m.ld(l == 1 ? W_G + 2 : W_G + 3))); });
+    m.run(6, [&](int L) {
+        const int l = L >> 1;
+        m.sth(W_G + 6 + l, L & 1, wide_half_mul(m.ld(l == 0 ? W_G + 1 : l == 1 ? W_TZ : W_TX), m.ld(l == 1 ? W_G + 2 : W_G + 3), L & 1));
+    });
     // round 4: G9 = x' = L H, G10 = U = (G - H) O, G11 = t1 = y E, G2 = z' = E z       (H = E + F - 2 G)
-    m.run(4, [&](int l) {
+    m.run(8, [&](int L) {
+        const int l = L >> 1;
         const F2 E = m.ld(W_G + 6), F = m.ld(W_G + 7), G = m.ld(W_G + 8);
         const F2 H = f2_norm(f2_sub(f2_add(E, F), f2_dbl(G)));
         const F2 a = m.ld(l == 0 ? W_G + 1 : l == 2 ? W_TY : W_G + 6), b = m.ld(l == 1 ? W_G : l == 2 ? W_G + 6 : W_TZ);
-        m.st(l == 3 ? W_G + 2 : W_G + 9 + l, f2_mul(f2_sel(l == 1, f2_norm(f2_sub(G, H)), a), f2_sel(l == 0, H, b)));
+        m.sth(l == 3 ? W_G + 2 : W_G + 9 + l, L & 1, wide_half_mul(f2_sel(l == 1, f2_norm(f2_sub(G, H)), a), f2_sel(l == 0, H, b), L & 1));
     });
     // linear: T <- (x', U - t1, z'),  c4 = M1 - M2
-    m.run(4, [&](int l) {
-        const F2 a = m.ld(l == 0 ? W_G + 9 : l == 1 ? W_G + 10 : l == 2 ? W_G + 2 : W_G + 4), b = m.ld(l == 1 ? W_G + 11 : W_G + 5);
-        m.st(l == 0 ? W_TX : l == 1 ? W_TY : l == 2 ? W_TZ : W_L4, f2_sel(l == 1 || l == 3, f2_norm(f2_sub(a, b)), a));
+    m.run(8, [&](int L) {
+        const int l = L >> 1, h = L & 1;
+        const Fe a = m.ldh(l == 0 ? W_G + 9 : l == 1 ? W_G + 10 : l == 2 ? W_G + 2 : W_G + 4, h), b = m.ldh(l == 1 ? W_G + 11 : W_G + 5, h);
+        m.sth(l == 0 ? W_TX : l == 1 ? W_TY : l == 2 ? W_TZ : W_L4, h, fe_sel(l == 1 || l == 3, fe_norm(fe_sub(a, b)), a));
     });
 }
 

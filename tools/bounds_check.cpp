@@ -8,6 +8,7 @@
 #define GPBC_BOUNDS
 #endif
 #include <cstring>
+#include <tuple>
 #include "../gopairingbasedcryptography_amd/csrc/curve29.hip.hpp"
 #include "../gopairingbasedcryptography_amd/csrc/pairing29.hip.hpp"
 #include "../gopairingbasedcryptography_amd/csrc/pairing29_pair.hip.hpp"
@@ -108,12 +109,16 @@ template <class F, class LoadA, class StoreA> static void msm_host(const uint8_t
 struct WideHost {
     std::vector<F2> s = std::vector<F2>(W_SLOTS, f2_zero());
     std::vector<std::pair<int, F2>> pending;
+    std::vector<std::tuple<int, int, Fe>> pending_half;
     F2 ld(int i) const { return s[i]; }
+    Fe ldh(int i, int h) const { return h ? s[i].a1 : s[i].a0; }
     void st(int i, const F2 &v) { pending.emplace_back(i, v); }
+    void sth(int i, int h, const Fe &v) { pending_half.emplace_back(i, h, v); }
     template <class B> void run(int n, B &&body) {
         for (int l = 0; l < n; l++) body(l);
         for (auto &p : pending) s[p.first] = p.second;
-        pending.clear();
+        for (auto &p : pending_half) (std::get<1>(p) ? s[std::get<0>(p)].a1 : s[std::get<0>(p)].a0) = std::get<2>(p);
+        pending.clear(); pending_half.clear();
     }
 };
 extern "C" {

@@ -64,6 +64,7 @@ def load():
         lib.gpbc_fixed_base_table_bytes.argtypes = [ctypes.c_size_t, ctypes.c_int]
         lib.gpbc_fixed_base_msm_workspace_bytes.restype = ctypes.c_size_t
         lib.gpbc_fixed_base_msm_workspace_bytes.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+        lib.gpbc_set_latency_path.argtypes = [ctypes.c_long]
         _lib = lib
     return _lib
 

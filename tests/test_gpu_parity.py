@@ -181,6 +181,26 @@ def test_pipelined_small_batches_match_the_two_kernel_form(eng, oracle):
     assert e1[5].tobytes() == o.gt_to_bytes(o.F12_ONE) and e1[64].tobytes() == o.gt_to_bytes(o.F12_ONE)
 
 
+def test_pair_primitives_cross_checked_on_the_device(eng, tmp_path):
+    """tools/check_pair_ops.hip: every lane-pair Fp12 primitive (product, squaring, sparse products, both cyclotomic squarings and a run)
+    against the single-lane tower, both computed by the same lanes ON the GPU.  The host interval harness proves the arithmetic, but
+    it has no DPP: round 3's v_subrev_u32_dpp miscompile (tools/subdpp_probe.hip) passed it and failed here."""
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    import os
+    exe = os.path.join(ROOT, "tools", "check_pair_ops")
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = os.path.join(ROOT, "tools", "check_pair_ops.hip")
+    hdrs = [os.path.join(ROOT, "gopairingbasedcryptography_amd", "csrc", f) for f in ("fe29.hip.hpp", "tower29.hip.hpp", "tower29_pair.hip.hpp")]
+    if not os.path.exists(exe) or any(os.path.getmtime(f) > os.path.getmtime(exe) for f in [src] + hdrs):
+        exe = str(tmp_path / "check_pair_ops")
+        subprocess.check_call([hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-I" + os.path.join(ROOT, "gopairingbasedcryptography_amd", "csrc"), src, "-o", exe],
+                              stderr=subprocess.DEVNULL, timeout=600)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "MISMATCH" not in out.stdout and out.stdout.count(" ok ") == 7, out.stdout + out.stderr
+
+
 def test_latency_path_matches_the_throughput_kernels(eng, oracle):
     """Calls of up to 2 048 pairings take the latency form (csrc/wide29.hip.hpp: one pairing per wavefront, the Miller loop as two waves
     passing lines through an LDS ring, Fp12 values as F2 slots in LDS).  Same bytes as the throughput kernels

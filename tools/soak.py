@@ -49,7 +49,16 @@ if n > 16384:                                                 # the same pairing
     for lo in range(0, n, 8192 + 37):
         hi = min(n, lo + 8192 + 37)
         assert (bn254.pair_batch(P.reshape(-1, 64)[lo:hi], Q.reshape(-1, 128)[lo:hi]).reshape(-1, 384) == want[lo:hi]).all(), "pipelined small batch"
-print("pairings ok  (%d, %.1f s)" % (n, time.time() - t0), flush=True)
+# ... and in calls of 1 .. 2048 pairs: the latency form (one pairing per wavefront, csrc/wide29.hip.hpp), sizes drawn at random
+want = gt.reshape(-1, 384)
+lo = 0
+n_wide_calls = 0
+while lo < min(n, 40000):
+    hi = min(n, lo + int(rng.integers(1, 2049)))
+    assert (bn254.pair_batch(P.reshape(-1, 64)[lo:hi], Q.reshape(-1, 128)[lo:hi]).reshape(-1, 384) == want[lo:hi]).all(), ("latency form", lo, hi)
+    lo = hi
+    n_wide_calls += 1
+print("pairings ok  (%d, %.1f s; %d calls through the latency form)" % (n, time.time() - t0, n_wide_calls), flush=True)
 t0 = time.time()
 lens = rng.integers(0, 12, size=n // 4)
 off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
@@ -57,6 +66,15 @@ m = int(off[-1])
 idx = rng.integers(0, n, size=m)
 Pm, Qm = P[idx], Q[idx]
 assert (bn254.multi_pair(Pm, Qm, off) == oracle_lib.multi_pair(Pm, Qm, off, threads=threads)).all(), "multi-pairing"
+# small multi-pairing calls (segment product + final exponentiation per wavefront): a few hundred pairs per call
+for trial in range(24):
+    ks = int(rng.integers(1, 40))
+    ls = rng.integers(0, 30, size=ks)
+    o2 = np.concatenate([[0], np.cumsum(ls)]).astype(np.uint64)
+    ii = rng.integers(0, n, size=int(o2[-1]))
+    if int(o2[-1]) == 0:
+        continue
+    assert (bn254.multi_pair(P[ii], Q[ii], o2) == oracle_lib.multi_pair(P[ii], Q[ii], o2, threads=threads)).all(), ("small multi-pairing", trial)
 print("multi-pairings ok  (%d segments, %d pairs, %.1f s)" % (len(lens), m, time.time() - t0), flush=True)
 t0 = time.time()
 ke = scal(4096, full=True)

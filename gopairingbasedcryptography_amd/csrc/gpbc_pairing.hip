@@ -689,6 +689,17 @@ static int pair_batch_one(const void *P, const void *Q, size_t n, void *gt_out) 
         if (rc != GPBC_OK) { (void)hipDeviceSynchronize(); return rc; }     // nothing may still use the buffers when they are freed
         return GPBC_OK;
     }
+    if (n <= g_wide_max.load()) {
+        // a latency call: its buffers come from the stream's scratch (level 3: the entries below use 0..2), not from six hipMalloc / hipFree
+        Scratch io;
+        TRY(io.open(nullptr, 3, Scratch::padded(n * GPBC_G1_BYTES) + Scratch::padded(n * GPBC_G2_BYTES) + Scratch::padded(n * GPBC_GT_BYTES)));
+        uint8_t *dP = io.take(n * GPBC_G1_BYTES), *dQ = io.take(n * GPBC_G2_BYTES), *dG = io.take(n * GPBC_GT_BYTES);
+        HIP_TRY(hipMemcpy(dP, P, n * GPBC_G1_BYTES, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(dQ, Q, n * GPBC_G2_BYTES, hipMemcpyHostToDevice));
+        TRY(gpbc_pair_batch_dev(dP, dQ, n, dG, nullptr));
+        HIP_TRY(hipMemcpy(gt_out, dG, n * GPBC_GT_BYTES, hipMemcpyDeviceToHost));       // (synchronises the null stream; the scratch lock is held until here)
+        return GPBC_OK;
+    }
     DevBuf dP, dQ, dG;
     TRY(dP.upload(P, n * GPBC_G1_BYTES)); TRY(dQ.upload(Q, n * GPBC_G2_BYTES)); TRY(dG.alloc(n * GPBC_GT_BYTES));
     TRY(gpbc_pair_batch_dev(dP.p, dQ.p, n, dG.p, nullptr));
@@ -913,6 +924,18 @@ int gpbc_multi_pair_hostseg_dev(const void *dP, const void *dQ, const uint64_t *
 }
 static int multi_pair_host_one(const void *P, const void *Q, const uint64_t *seg_off, size_t k, size_t n_pairs, void *gt_out, uint8_t *ok_out) {
     TRY(bind_device());
+    if (k <= g_wide_max.load() && n_pairs <= g_wide_max.load() && n_pairs) {
+        // a latency call (Pair / PairingCheck as the reference makes them): buffers from the stream's scratch, level 3
+        Scratch io;
+        TRY(io.open(nullptr, 3, Scratch::padded(n_pairs * GPBC_G1_BYTES) + Scratch::padded(n_pairs * GPBC_G2_BYTES) + Scratch::padded(k * GPBC_GT_BYTES) + Scratch::padded(k)));
+        uint8_t *dP = io.take(n_pairs * GPBC_G1_BYTES), *dQ = io.take(n_pairs * GPBC_G2_BYTES), *dG = io.take(k * GPBC_GT_BYTES), *dOk = io.take(k);
+        HIP_TRY(hipMemcpy(dP, P, n_pairs * GPBC_G1_BYTES, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(dQ, Q, n_pairs * GPBC_G2_BYTES, hipMemcpyHostToDevice));
+        TRY(multi_pair_core(dP, dQ, seg_off, k, n_pairs, dG, ok_out ? dOk : nullptr, nullptr));
+        if (gt_out) HIP_TRY(hipMemcpy(gt_out, dG, k * GPBC_GT_BYTES, hipMemcpyDeviceToHost));
+        if (ok_out) HIP_TRY(hipMemcpy(ok_out, dOk, k, hipMemcpyDeviceToHost));
+        return GPBC_OK;
+    }
     DevBuf dP, dQ, dG, dOk;
     TRY(dP.upload(P, n_pairs * GPBC_G1_BYTES)); TRY(dQ.upload(Q, n_pairs * GPBC_G2_BYTES));
     TRY(dG.alloc(k * GPBC_GT_BYTES));

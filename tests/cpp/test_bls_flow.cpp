@@ -55,6 +55,19 @@ int main() {
     EXPECT(e2.Equal(sq) && e2b.Equal(sq));
     GT ex; ex.Exp(e, Scalar(2)); EXPECT(ex.Equal(sq));
     GT q; q.Div(sq, e); EXPECT(q.Equal(e));
+    // the singles of the mirror the reference calls one at a time: GT.Inverse (access/tree/access_tree_node.go:157), generator
+    // multiplications through the lazily built fixed-base tables against the variable-base kernel, HashToG1 with an EMPTY tag
+    {
+        GT inv, prod, one; inv.Inverse(e); prod.Mul(e, inv); one.Div(e, e);
+        EXPECT(prod.Equal(one));
+        for (uint64_t k : {0ull, 1ull, 5ull, 0xFFFFFFFFFFFFFFFFull}) {
+            G1Affine b1, v1; b1.ScalarMultiplicationBase(Scalar(k)); v1.ScalarMultiplication(g1, Scalar(k));
+            G2Affine b2, v2; b2.ScalarMultiplicationBase(Scalar(k)); v2.ScalarMultiplication(g2, Scalar(k));
+            EXPECT(b1.Equal(v1) && b2.Equal(v2));
+        }
+        G1Affine h0 = HashToG1("abc", ""), h1 = HashToG1("abc", "d");
+        EXPECT(!h0.IsInfinity() && !h0.Equal(h1) && h0.Equal(HashToG1("abc", "")));
+    }
     bool threw = false;
     try { Pair({g1, g1}, {g2}); } catch (const std::invalid_argument &) { threw = true; }
     EXPECT(threw);                                               // "invalid inputs sizes"

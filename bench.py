@@ -132,7 +132,11 @@ def main():
     # Rehearsal of the N > 1 control flow on a ONE-GPU box (GPBC_BENCH_REHEARSAL=1): every rank uses device 0, torch.distributed
     # runs on gloo and the library's RCCL communicator is skipped (RCCL refuses two ranks on one device), so the legs that need
     # the all-gather report an error entry.  Never a measurement: the line says so in config.rehearsal.
-    rehearsal = use_dist and os.environ.get("GPBC_BENCH_REHEARSAL") == "1"
+    # GPBC_BENCH_REHEARSAL=stub: the same, but WITH the library communicator — over tests/stub_rccl's librccl.so.1 (a test double that
+    # rendezvouses the ranks' processes in shared memory), which must be on LD_LIBRARY_PATH: gpbc_comm_init_rank with N > 1 ranks and the
+    # all-gather legs run for real, only the transport is not RCCL.
+    rehearsal = use_dist and os.environ.get("GPBC_BENCH_REHEARSAL") in ("1", "stub")
+    rehearsal_stub = rehearsal and os.environ.get("GPBC_BENCH_REHEARSAL") == "stub"
     if rehearsal:
         local_rank = 0
     if use_dist:
@@ -163,8 +167,8 @@ def main():
         dist.barrier()
     bn254.init(local_rank)
     lib = _lib.load()
-    comm_error = "rehearsal on one GPU: library communicator skipped" if rehearsal else None
-    if use_dist and not rehearsal:
+    comm_error = "rehearsal on one GPU: library communicator skipped" if (rehearsal and not rehearsal_stub) else None
+    if use_dist and (not rehearsal or rehearsal_stub):
         # the library's own RCCL communicator over the same ranks (the all-gather of partial sums / GT rows)
         sys.stdout.flush()
         saved_stdout = os.dup(1)
@@ -241,7 +245,8 @@ def main():
     _lib.check(lib.gpbc_valu_probe(probe))
     peak_now, clock_hz = probe[0] / 1e12, probe[1]
     n_simd = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
-    miller_ms = sum(kern[k]["ms_per_step"] for k in ("k_miller_lines", "k_miller_accumulate") if k in kern)
+    # small --batch values take the pipelined or the latency kernel instead of the lines/accumulate pair: count whichever ran
+    miller_ms = sum(v["ms_per_step"] for k, v in kern.items() if k in ("k_miller_lines", "k_miller_accumulate", "k_miller_pipelined", "k_miller_wide")) or float("nan")
     fexp_ms = kern.get("k_final_exp", {}).get("ms_per_step", float("nan"))
 
     # ---- every rank checks a sample of its own outputs against the oracle (the parity claim of the workload string)
@@ -267,7 +272,8 @@ def main():
                    "arithmetic": "254-bit Montgomery integers as 9 signed 29-bit limbs (int32), 32x32+64-bit MACs into int64 columns"},
     }
     if rehearsal:
-        result["config"]["rehearsal"] = "NOT A MEASUREMENT: %d ranks share one GPU (GPBC_BENCH_REHEARSAL=1), gloo, no library communicator" % world
+        result["config"]["rehearsal"] = ("NOT A MEASUREMENT: %d ranks share one GPU (GPBC_BENCH_REHEARSAL), torch.distributed on gloo, " % world) + \
+            ("library communicator over the rccl TEST DOUBLE of tests/stub_rccl" if rehearsal_stub else "no library communicator")
     # ---- roofline, VALU integer-MAC bound: the single kernel with the largest time per step
     frac = lambda fpmul, t_ms: fpmul * MAC_PER_FP_MUL * B / (t_ms * 1e-3) / 1e12 / PEAK_TMAC_PER_S
     # VALU instructions per wave of the same kernels from the last committed PMC pass (tools/pmc_run.sh -> profiles/pmc_counters.json):
@@ -446,8 +452,8 @@ def main():
             return {"workload": "configs[2]: BLS aggregate verification of %d signatures on one message point, random linear "
                                 "combination with 128-bit scalars" % n_total, "signatures": n_total, "scaling": "strong",
                     "signatures_per_s": n_total / t_lit, "ms": 1e3 * t_lit,
-                    "timed": "sum rho_i pk_i over 2^20 public keys (bucket multi-scalar multiplication: the result of 2^20 G1 scalar-mults + their sum%s) + the 2-pairing check"
-                             % (" + RCCL all-gather of the partial sums inside the library" if world > 1 else ""),
+                    "timed": "sum rho_i pk_i over %d public keys (bucket multi-scalar multiplication: the result of that many G1 scalar-mults + their sum%s) + the 2-pairing check"
+                             % (n_total, " + RCCL all-gather of the partial sums inside the library" if world > 1 else ""),
                     "with_g2_sums_signatures_per_s": n_total / t_full, "with_g2_sums_ms": 1e3 * t_full,
                     "accepts": all_ranks_true(ok and ok2), "rejects_forged": all_ranks_true(rejected),
                     "collective": ("library RCCL all-gather, %d ranks" % bn254.comm_ranks()) if world > 1 else None}

@@ -3,6 +3,7 @@
 // communicator(s) and the all-gather entries, the per-(device, stream) internal workspace, and the field-level test
 // entry.  gfx950 only.
 #include "gpbc_common.hpp"
+#include <cstdlib>
 #include <dlfcn.h>
 #include <rccl/rccl.h>      // types and enums only: the library is opened with dlopen when a communicator is first asked for
 #include <string>
@@ -177,7 +178,14 @@ static int g_comm_rank0 = 0;          // mode 2: this process's rank
 static int rccl_load() {
     if (g_rccl.handle) return GPBC_OK;
     void *h = nullptr;
-    for (const char *name : {"librccl.so", "librccl.so.1"}) if ((h = dlopen(name, RTLD_NOW | RTLD_NOLOAD))) break;
+    // GPBC_RCCL_LIBRARY names one library file to use instead (a particular RCCL build; tests/stub_rccl's test double in bench.py's
+    // one-GPU rehearsal, where PyTorch's real RCCL is already in the process and would refuse two ranks on one device)
+    const char *override_path = getenv("GPBC_RCCL_LIBRARY");
+    if (override_path && *override_path) {
+        h = dlopen(override_path, RTLD_NOW | RTLD_LOCAL);
+        if (!h) return fail(GPBC_ERR_COMM, "GPBC_RCCL_LIBRARY=%s: %s", override_path, dlerror());
+    }
+    if (!h) for (const char *name : {"librccl.so", "librccl.so.1"}) if ((h = dlopen(name, RTLD_NOW | RTLD_NOLOAD))) break;
     if (!h) for (const char *name : {"librccl.so.1", "librccl.so"}) if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
     if (!h) return fail(GPBC_ERR_COMM, "RCCL not found (dlopen librccl.so.1): %s", dlerror());
     Rccl r;

@@ -80,7 +80,8 @@ int gpbc_abi_version(void);
  * The path has exactly one exchange step: an all-gather of byte rows — 192 B of partial sums per rank in
  * the aggregate-verify path (BASELINE config 3), n/G x 384 B of GT values per rank in batched decryption (config 5).
  * RCCL is opened with dlopen when a communicator is first requested (an RCCL already loaded in the process, e.g. PyTorch's,
- * is reused); without it these entries fail with GPBC_ERR_COMM and everything else works.
+ * is reused; the environment variable GPBC_RCCL_LIBRARY names one library file to open instead); without it these entries fail
+ * with GPBC_ERR_COMM and everything else works.
  *   one process, all bound devices:   gpbc_comm_init_all()  -> rank = device index, gpbc_allgather_all_dev()
  *   one process per GPU (torchrun):   rank 0 calls gpbc_comm_get_unique_id(), the launcher broadcasts the 128 bytes, every
  *                                     process calls gpbc_comm_init_rank(id, n_ranks, rank) -> gpbc_allgather_dev()

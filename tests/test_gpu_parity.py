@@ -492,6 +492,35 @@ def test_collective_paths_with_two_ranks_on_a_test_double(eng, tmp_path):
     assert "scalar_mul_sum_dev on 2 rank(s)" in out.stdout and "BLS aggregate verify over 2 rank(s)" in out.stdout, out.stdout
 
 
+def test_two_process_ranks_over_the_test_double(eng, tmp_path):
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), rehearsed on this one GPU with the
+    library communicator over tests/stub_rccl (GPBC_BENCH_REHEARSAL=stub, GPBC_RCCL_LIBRARY): gpbc_comm_get_unique_id ->
+    gpbc_comm_init_rank with TWO ranks -> gpbc_allgather_dev / gpbc_g1_scalar_mul_sum_dev inside the three strong-scaling legs
+    (aggregate verification, BSW07 decrypt, AFP25 decrypt + all-gather of the GT masks), each checked by the bench itself.  Not a
+    measurement — it shows the N > 1 code of the C library and of bench.py runs and returns right answers."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    import os
+    stub = str(tmp_path / "librccl.so.1")
+    subprocess.check_call(["g++", "-O1", "-shared", "-fPIC", "-pthread", "-w", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           os.path.join(ROOT, "tests", "stub_rccl", "rccl_stub.cpp"), "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-o", stub])
+    env = dict(os.environ, GPBC_BENCH_REHEARSAL="stub", GPBC_RCCL_LIBRARY=stub, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29531",
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "16384", "--config-scale", "64", "--no-cpu"],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and "TEST DOUBLE" in line["config"]["rehearsal"]
+    legs = line["secondary"]["configs"]
+    assert legs.get("comm_error") is None, legs
+    for name in ("aggregate_verify_2^20", "bsw07_256of256_2^16", "afp25_2^18"):
+        assert "error" not in legs[name], (name, legs[name])
+    assert legs["aggregate_verify_2^20"]["accepts"] and legs["aggregate_verify_2^20"]["rejects_forged"]
+    assert legs["afp25_2^18"]["all_messages_recovered"] and legs["afp25_2^18"]["collective"]
+
+
 def test_large_batch_chunks_and_properties(eng, oracle):
     """BASELINE size (2^20 would take the oracle ~1 min on one core, so 2^18 + 5 pairs here: more than one lines-workspace
     chunk of 262144, ragged tail): HBM-resident path, spot-checked against the oracle at chunk boundaries, plus

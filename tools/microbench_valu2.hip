@@ -10,13 +10,14 @@ typedef unsigned long long u64;
 typedef unsigned int u32;
 
 enum Op { ADD_VOP2, ADD_LIT, AND_LIT, AND_SGPR, AND_VGPR, ASHR_INL, LSHL_INL, SUB_VOP2, MOV_VOP1, MOV_DPP, ADD_DPP, CND_E32, CND_E64,
-          BFE_I32, ALIGNBIT, ADD3, LSHL_ADD, AND_OR, MAD_I64, MAD_PLUS_ADD, MAD_PLUS_ANDLIT, MAD_PLUS_ADD3, NORM_TRIPLE, NORM_TRIPLE_SGPR, N_OPS };
+          BFE_I32, ALIGNBIT, ADD3, LSHL_ADD, AND_OR, MAD_I64, MAD_PLUS_ADD, MAD_PLUS_ANDLIT, MAD_PLUS_ADD3, NORM_TRIPLE, NORM_TRIPLE_SGPR, CND_E32_VCCSET, CND_E64_VCC, CND_E32_AFTER_CMP, BFI_B32, N_OPS };
 static const char *NAME[N_OPS] = {"v_add_u32 (VOP2)", "v_add_u32 + literal", "v_and_b32 + literal", "v_and_b32 sgpr mask", "v_and_b32 vgpr mask",
     "v_ashrrev_i32 inline 29", "v_lshlrev_b32 inline", "v_sub_u32 (VOP2)", "v_mov_b32 (VOP1)", "v_mov_b32_dpp quad_perm", "v_add_u32_dpp quad_perm",
     "v_cndmask_b32_e32 (vcc)", "v_cndmask_b32_e64 (sgpr pair)", "v_bfe_i32 (VOP3)", "v_alignbit_b32 (VOP3)", "v_add3_u32 (VOP3)",
     "v_lshl_add_u32 (VOP3)", "v_and_or_b32 (VOP3)", "v_mad_i64_i32", "mad + v_add_u32", "mad + v_and literal", "mad + v_add3",
-    "ashr + and-literal + add", "ashr + and-sgpr + add"};
-static const int INSTR[N_OPS] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 3, 3};
+    "ashr + and-literal + add", "ashr + and-sgpr + add", "v_cndmask_b32_e32, vcc set by s_mov", "v_cndmask_b32_e64 with vcc", "v_cmp + 8 x v_cndmask_b32_e32",
+    "v_bfi_b32 (VOP3)"};
+static const int INSTR[N_OPS] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 3, 3, 1, 1, 1, 1};
 
 template <int OP>
 __device__ __forceinline__ void step(u64 &acc, u32 &x, u32 &y, u32 a, u32 b, u32 smask) {
@@ -43,6 +44,10 @@ __device__ __forceinline__ void step(u64 &acc, u32 &x, u32 &y, u32 a, u32 b, u32
     else if constexpr (OP == MAD_PLUS_ANDLIT) asm volatile("v_mad_i64_i32 %0, vcc, %2, %3, %0\n\tv_and_b32 %1, 0x1fffffff, %1" : "+v"(acc), "+v"(x) : "v"(a), "v"(b) : "vcc");
     else if constexpr (OP == MAD_PLUS_ADD3) asm volatile("v_mad_i64_i32 %0, vcc, %2, %3, %0\n\tv_add3_u32 %1, %1, %2, %3" : "+v"(acc), "+v"(x) : "v"(a), "v"(b) : "vcc");
     else if constexpr (OP == NORM_TRIPLE) asm volatile("v_ashrrev_i32 %1, 29, %0\n\tv_and_b32 %0, 0x1fffffff, %0\n\tv_add_u32 %0, %0, %1" : "+v"(x), "+v"(y));
+    else if constexpr (OP == CND_E32_VCCSET) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(x) : "v"(a) : );
+    else if constexpr (OP == CND_E64_VCC) asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"(x) : "v"(a) : );
+    else if constexpr (OP == CND_E32_AFTER_CMP) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(x) : "v"(a) : );
+    else if constexpr (OP == BFI_B32) asm volatile("v_bfi_b32 %0, %1, %2, %0" : "+v"(x) : "v"(a), "v"(b));
     else if constexpr (OP == NORM_TRIPLE_SGPR) asm volatile("v_ashrrev_i32 %1, 29, %0\n\tv_and_b32 %0, %2, %0\n\tv_add_u32 %0, %0, %1" : "+v"(x), "+v"(y) : "s"(smask));
 }
 
@@ -51,9 +56,11 @@ __global__ void __launch_bounds__(256) bench_kernel(u64 *out, int iters, u32 a, 
     u64 acc[CHAINS]; u32 x[CHAINS], y[CHAINS];
 #pragma unroll
     for (int c = 0; c < CHAINS; c++) { acc[c] = threadIdx.x + c; x[c] = threadIdx.x * 7 + c; y[c] = c; }
+    if constexpr (OP == CND_E32_VCCSET || OP == CND_E64_VCC) asm volatile("s_mov_b64 vcc, 0x55" ::: "vcc");
     for (int i = 0; i < iters; i++) {
 #pragma unroll
         for (int u = 0; u < 8; u++) {
+            if constexpr (OP == CND_E32_AFTER_CMP) asm volatile("v_cmp_gt_u32 vcc, %0, %1" :: "v"(x[0]), "v"(a) : "vcc");
 #pragma unroll
             for (int c = 0; c < CHAINS; c++) step<OP>(acc[c], x[c], y[c], a, b, smask);
         }

@@ -360,11 +360,34 @@ GPBC_KERNEL k_final_exp_wide(const uint8_t *f_in, uint8_t *gt_out, size_t n) {
     m.run(6, [&](int k) { f2_store(gt_out + i * GPBC_GT_BYTES + 64 * k, m.ld(k)); });
 }
 
+// Long segments of a latency call (one BSW07 ciphertext is 513 pairs, a BB04 identity 257): `fold` wavefronts per segment each
+// multiply one residue class of the segment's Miller values — lo + s, lo + s + fold, ... — and leave the product in place at lo + s,
+// so that the wavefront of k_segment_final_exp_wide multiplies `fold` values instead of the whole run.  Same clamping of the table.
+GPBC_KERNEL k_segment_fold_wide(uint8_t *f, const uint64_t *__restrict__ seg_off, size_t k, size_t n_vals, unsigned fold) {
+    __shared__ w128 w_mem[W_SLOTS * 6];
+    const size_t j = blockIdx.x / fold;
+    const uint64_t s = blockIdx.x % fold;
+    if (j >= k) return;
+    uint64_t lo = seg_off[j], hi = seg_off[j + 1];
+    if (hi > n_vals) hi = n_vals;
+    if (lo > hi) lo = hi;
+    if (hi - lo <= s + fold) return;                        // this class holds at most one value: it stays where it is
+    const WideLds m{w_mem, (int)threadIdx.x};
+    m.run(6, [&](int c) { m.st(c, f2_load(f + (lo + s) * GPBC_GT_BYTES + 64 * c)); });
+    for (uint64_t i = lo + s + fold; i < hi; i += fold) {
+        m.run(6, [&](int c) { m.st(wv(1) + c, f2_load(f + i * GPBC_GT_BYTES + 64 * c)); });
+        wide_mul(m, wv(0), wv(0), wv(1));
+    }
+    m.run(6, [&](int c) { f2_store(f + (lo + s) * GPBC_GT_BYTES + 64 * c, m.ld(c)); });
+}
+
 // The product of a segment's Miller values and its final exponentiation in one launch, one segment per wavefront: what
 // k_segment_product (one lane, serial Fp12 products) + k_final_exp_wide do for the small calls of the latency path.  Same clamping
 // of the table and the same echo (first value, values consumed) as k_segment_product.
+// `fold` > 0: k_segment_fold_wide ran first with that many residue classes, so the segment's product is the product of its first
+// `fold` values.
 GPBC_KERNEL k_segment_final_exp_wide(const uint8_t *__restrict__ f, const uint64_t *__restrict__ seg_off, uint8_t *__restrict__ out, size_t k, size_t n_vals,
-                                     uint64_t *__restrict__ echo) {
+                                     uint64_t *__restrict__ echo, unsigned fold) {
     __shared__ w128 w_mem[W_SLOTS * 6];
     const size_t j = blockIdx.x;
     if (j >= k) return;
@@ -372,9 +395,10 @@ GPBC_KERNEL k_segment_final_exp_wide(const uint8_t *__restrict__ f, const uint64
     uint64_t lo = seg_off[j], hi = seg_off[j + 1];
     if (hi > n_vals) hi = n_vals;
     if (lo > hi) lo = hi;
+    const uint64_t end = (fold && hi - lo > fold) ? lo + fold : hi;
     if (lo == hi) m.run(6, [&](int c) { m.st(c, f2_sel(c == 0, f2_one(), f2_zero())); });
     else m.run(6, [&](int c) { m.st(c, f2_load(f + lo * GPBC_GT_BYTES + 64 * c)); });
-    for (uint64_t i = lo + 1; i < hi; i++) {
+    for (uint64_t i = lo + 1; i < end; i++) {
         m.run(6, [&](int c) { m.st(wv(1) + c, f2_load(f + i * GPBC_GT_BYTES + 64 * c)); });
         wide_mul(m, wv(0), wv(0), wv(1));
     }
@@ -470,6 +494,20 @@ GPBC_KERNEL k_gt_exp(const uint8_t *__restrict__ x, const uint8_t *__restrict__ 
     uint32_t k[8];
     load_scalar(k, kk + i * GPBC_SCALAR_BYTES);
     f6_store(out + off, f12p_exp256(px, f6_load(x + off), k, tabws + lane * (size_t)GT_EXP_TAB_DWORDS));
+}
+
+// the same for the calls of the latency path: one element per wavefront (wide_exp256)
+GPBC_KERNEL k_gt_exp_wide(const uint8_t *__restrict__ x, const uint8_t *__restrict__ kk, uint8_t *__restrict__ out, size_t n) {
+    __shared__ w128 w_mem[W_SLOTS * 6];
+    const size_t i = blockIdx.x;
+    if (i >= n) return;
+    const WideLds m{w_mem, (int)threadIdx.x};
+    uint32_t k[8];
+#pragma unroll
+    for (int w = 0; w < 8; w++) k[w] = __builtin_amdgcn_readfirstlane(reinterpret_cast<const uint32_t *>(kk + i * GPBC_SCALAR_BYTES)[w]);
+    m.run(6, [&](int c) { m.st(wv(1) + c, f2_load(x + i * GPBC_GT_BYTES + 64 * c)); });
+    wide_exp256(m, k);
+    m.run(6, [&](int c) { f2_store(out + i * GPBC_GT_BYTES + 64 * c, m.ld(c)); });
 }
 
 // op 0: a*b   1: a*b^-1   2: a^-1
@@ -570,7 +608,15 @@ static int multi_pair_dev_echo(const void *dP, const void *dQ, const uint64_t *d
     if (workspace_bytes < gpbc_multi_pair_workspace_bytes(n_pairs, k)) return fail(GPBC_ERR_WORKSPACE, "workspace too small");
     TRY(gpbc_miller_loop_dev(dP, dQ, n_pairs, d_workspace, stream));
     if (k <= g_wide_max.load() && n_pairs <= g_wide_max.load()) {              // the latency path: product and exponentiation per wavefront
-        k_segment_final_exp_wide<<<(unsigned)k, BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_workspace, d_seg_off, (uint8_t *)d_gt_out, k, n_pairs, d_echo);
+        // segments of 32 values and more on average: fold them over 8 or 16 wavefronts first (a device-resident table is not
+        // known here, so the average decides; a skewed table only makes the choice slower or faster, never wrong)
+        const unsigned fold = n_pairs >= 128 * k ? 16u : n_pairs >= 32 * k ? 8u : 0u;
+        if (fold) {
+            k_segment_fold_wide<<<(unsigned)(k * fold), BLOCK, 0, (hipStream_t)stream>>>((uint8_t *)d_workspace, d_seg_off, k, n_pairs, fold);
+            TRY(check_launch("k_segment_fold_wide"));
+            profile_mark("k_segment_fold_wide", (hipStream_t)stream);
+        }
+        k_segment_final_exp_wide<<<(unsigned)k, BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_workspace, d_seg_off, (uint8_t *)d_gt_out, k, n_pairs, d_echo, fold);
         TRY(check_launch("k_segment_final_exp_wide"));
         profile_mark("k_segment_final_exp_wide", (hipStream_t)stream);
         return GPBC_OK;
@@ -607,6 +653,12 @@ int gpbc_gt_exp_batch_dev(const void *d_x, const void *d_k, size_t n, void *d_ou
     if (!d_x || !d_k || !d_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
     TRY(bind_device());
     hipStream_t st = (hipStream_t)stream;
+    if (n <= g_wide_max.load()) {
+        k_gt_exp_wide<<<(unsigned)n, BLOCK, 0, st>>>((const uint8_t *)d_x, (const uint8_t *)d_k, (uint8_t *)d_out, n);
+        TRY(check_launch("k_gt_exp_wide"));
+        profile_mark("k_gt_exp_wide", st);
+        return GPBC_OK;
+    }
     constexpr size_t CHUNK = 131072;                       // elements per launch: 1 GB of window tables (4 KB per lane)
     const size_t chunk = n < CHUNK ? n : CHUNK;
     std::lock_guard<std::mutex> seq(g_ws_seq_mu);

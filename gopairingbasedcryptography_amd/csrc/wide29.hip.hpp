@@ -341,5 +341,26 @@ template <class M> GPBC_INLINE void wide_final_exp(M &m) {
     wide_mul(m, F, T2, T0);
 }
 
+// ---- GT.Exp for the latency path: value 0 <- x^k for a 256-bit plain exponent (k = 0 -> one), x any Fp12 element (gnark's Exp is the
+// generic square-and-multiply, and callers hand it values outside the cyclotomic subgroup too).  Three-bit windows from the top over
+// the table x^1 .. x^7 in values 1..7; the exponent is the same for every lane of the wavefront, so the digit branches are uniform.
+template <class M> GPBC_INLINE void wide_exp256(M &m, const uint32_t (&k)[8]) {
+    constexpr int Z = wv(0);
+    for (int e = 2; e < 8; e++) wide_mul(m, wv(e), wv(e - 1), wv(1));
+    bool started = false;
+    for (int w = 85; w >= 0; w--) {
+        const int bit = 3 * w, word = bit >> 5, sh = bit & 31;
+        uint32_t d = k[word] >> sh;
+        if (sh > 29 && word < 7) d |= k[word + 1] << (32 - sh);
+        d &= 7u;
+        if (started) for (int q = 0; q < 3; q++) wide_mul(m, Z, Z, Z);
+        if (d) {
+            if (started) wide_mul(m, Z, Z, wv((int)d));
+            else { wide_copy(m, Z, wv((int)d)); started = true; }
+        }
+    }
+    if (!started) m.run(6, [&](int c) { m.st(Z + c, f2_sel(c == 0, f2_one(), f2_zero())); });
+}
+
 }  // namespace gpbc
 #endif

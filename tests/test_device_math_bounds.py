@@ -326,3 +326,10 @@ def test_wide_latency_form_under_bounds(hc, oracle):
     P0 = P.copy(); P0[1] = 0
     hc.hc_pair_wide(vp(P0), vp(Q), ctypes.c_size_t(n), vp(gt), ctypes.c_int(1))
     assert (gt == oracle.pair_batch(P0, Q)).all()
+    # GT.Exp of the latency form (wide_exp256) on a pairing value and on Miller values (outside the cyclotomic subgroup): the chain of
+    # general products z <- z z, z <- z x^d must hold its bounds for any exponent, the all-ones one included
+    x = np.ascontiguousarray(np.concatenate([ref[:1], f[:2]]))
+    ks = np.frombuffer(b"".join(e.to_bytes(32, "little") for e in ((1 << 256) - 1, o.bench_scalar("wide-exp", 0), 0)), dtype=np.uint8).copy()
+    got = np.zeros((3, 384), dtype=np.uint8)
+    hc.hc_gt_exp_wide(vp(x), vp(ks), ctypes.c_size_t(3), vp(got))
+    assert (got == oracle.gt_exp(x, ks, threads=3)).all()

@@ -238,11 +238,19 @@ def test_latency_path_matches_the_throughput_kernels(eng, oracle):
             if knob == 0:
                 want_long = got
             assert (got == want_long).all(), knob
+            # segments of 128 values and more on average are folded over 16 wavefronts before the exponentiation (k_segment_fold_wide):
+            # lengths below, at and one above the fold, a long one, and a single BSW07-sized segment of 513 pairs
+            ragged = np.array([0, 5, 21, 38, 600], dtype=np.uint64)
+            got_r, got_1 = eng.multi_pair(P[:600], Q[:600], ragged), eng.multi_pair(P[:513], Q[:513], np.array([0, 513], dtype=np.uint64))
+            if knob == 0:
+                want_r, want_1 = got_r, got_1
+            assert (got_r == want_r).all() and (got_1 == want_1).all(), knob
     finally:
         lib.gpbc_set_latency_path(2048)
     assert (e1[:64] == oracle.pair_batch(P[:64], Q[:64], threads=8)).all()
     assert e1[3].tobytes() == o.gt_to_bytes(o.F12_ONE) and e1[70].tobytes() == o.gt_to_bytes(o.F12_ONE)
     assert (want_long == oracle.multi_pair(P[:301], Q[:301], long_seg, threads=8)).all()
+    assert (want_r == oracle.multi_pair(P[:600], Q[:600], ragged, threads=8)).all()
 
 
 def test_multi_pair_fixed_q(eng, oracle, synth):
@@ -368,10 +376,25 @@ def test_gt_ops_golden(eng):
 
 
 def test_gt_exp_vs_oracle(eng, oracle, synth):
+    """GT.Exp through both forms — one element per lane pair (gpbc_set_latency_path(0)) and one per wavefront (calls of up to 2 048
+    elements, wide_exp256) — on pairing values and on Miller values (Fp12 elements OUTSIDE the cyclotomic subgroup: gnark's Exp is the
+    generic square-and-multiply), with the edge exponents 0, 1, 2, 7, 8, r - 1, r, 2^255 and 2^256 - 1 among random ones."""
+    from gopairingbasedcryptography_amd import _lib
+    lib = _lib.load()
     P, Q = synth[0][:40], synth[1][:40]
     gt = eng.pair_batch(P, Q)
-    k = scalars("gtexp", 40)
-    assert (eng.gt_exp(gt, k) == oracle.gt_exp(gt, k, threads=8)).all()
+    gt[20:] = eng.miller_loop(P[20:], Q[20:])
+    k = scalars("gtexp", 40).reshape(40, 32).copy()
+    for i, e in enumerate((0, 1, 2, 7, 8, o.R - 1, o.R, 1 << 255, (1 << 256) - 1)):
+        k[i] = k[20 + i] = np.frombuffer(e.to_bytes(32, "little"), dtype=np.uint8)
+    want = oracle.gt_exp(gt, k.reshape(-1), threads=8)
+    try:
+        for knob in (0, 2048):
+            _lib.check(lib.gpbc_set_latency_path(knob))
+            assert (eng.gt_exp(gt, k.reshape(-1)) == want).all(), knob
+            assert (eng.gt_exp(gt[:1], k[:1].reshape(-1)) == want[:1]).all() and (eng.gt_exp(gt[3:4], k[3:4].reshape(-1)) == want[3:4]).all(), knob
+    finally:
+        lib.gpbc_set_latency_path(2048)
 
 
 def test_bilinearity_property(eng, synth):

@@ -141,6 +141,18 @@ void hc_pair_wide(const uint8_t *P, const uint8_t *Q, size_t n, uint8_t *out, in
         stats_flush();
     }
 }
+// GT.Exp of the latency form (k_gt_exp_wide): x any Fp12 element, k a 256-bit plain exponent
+void hc_gt_exp_wide(const uint8_t *x, const uint8_t *k, size_t n, uint8_t *out) {
+    for (size_t i = 0; i < n; i++) {
+        WideHost m;
+        uint32_t kw[8];
+        memcpy(kw, k + 32 * i, 32);
+        for (int c = 0; c < 6; c++) m.s[wv(1) + c] = f2_load(x + 384 * i + 64 * c);
+        wide_exp256(m, kw);
+        for (int c = 0; c < 6; c++) f2_store(out + 384 * i + 64 * c, m.s[c]);
+        stats_flush();
+    }
+}
 void hc_pair(const uint8_t *P, const uint8_t *Q, size_t n, uint8_t *out) {
     for (size_t i = 0; i < n; i++) {
         const uint8_t *p = P + 64 * i, *q = Q + 128 * i;

@@ -34,3 +34,25 @@ for n in (1, 2, 64):
     for _ in range(10):
         e = bn254.final_exp(f); torch.cuda.synchronize()
     print("  final_exp alone", n, "%.3f ms" % ((time.perf_counter() - t0) / 10 * 1e3))
+
+# the other single calls the reference makes one at a time: what ONE call costs through the host-pointer API
+rng = np.random.default_rng(7)
+k1 = bn254.scalars_to_bytes([int.from_bytes(rng.bytes(31), "little")])
+gt1 = bn254.pair_batch(g1[None], g2[None])
+def timed(name, fn, reps=5):
+    fn()
+    t0 = time.perf_counter()
+    for _ in range(reps): fn()
+    print("%-44s %.3f ms" % (name, (time.perf_counter() - t0) / reps * 1e3))
+timed("g1_scalar_mul, 1 point", lambda: bn254.g1_scalar_mul(g1[None], k1))
+timed("g2_scalar_mul, 1 point", lambda: bn254.g2_scalar_mul(g2[None], k1))
+timed("g1_scalar_mul_base, 1 scalar", lambda: bn254.g1_scalar_mul_base(k1))
+timed("g2_scalar_mul_base, 1 scalar", lambda: bn254.g2_scalar_mul_base(k1))
+timed("gt_exp, 1 element", lambda: bn254.gt_exp(gt1, k1))
+timed("gt_mul, 1 element", lambda: bn254.gt_mul(gt1, gt1))
+timed("gt_div, 1 element", lambda: bn254.gt_div(gt1, gt1))
+timed("hash_to_g1, 1 message of 32 bytes", lambda: bn254.hash_to_g1([b"m" * 32], b"Hash Bytes To Element In G1"))
+timed("hash_to_g2, 1 message of 32 bytes", lambda: bn254.hash_to_g2([b"m" * 32], b"Hash Bytes To Element In G2"))
+for m in (3, 513):
+    P = np.repeat(g1[None], m, 0); Q = np.repeat(g2[None], m, 0)
+    timed("multi_pair, 1 segment of %d pairs" % m, lambda: bn254.multi_pair(P, Q, np.array([0, m], dtype=np.uint64)))

@@ -11,7 +11,11 @@ namespace gpbc {
 // Phase B of the Miller loop on a lane pair; next() yields the 88 lines in order (both lanes read the same line).
 // (Folding the tangent and the chord of a non-zero NAF digit into one full product, as miller_accumulate_multi does for the lines
 // of two pairs, was measured on this kernel and is SLOWER here: k_miller_accumulate 56.9 -> 67.1 ms per 2^20 pairings — the 23
-// extra inlined full products and value reductions cost more in registers and code than the 4 F2 products they save.)
+// extra inlined full products and value reductions cost more in registers and code than the 4 F2 products they save.  Round 3 tried
+// it again with the full product as a CALL through memory, like final_exp_pair's: 894 k instead of 922 k VALU instructions per wave,
+// but the operands' round trips through private memory doubled the wait share (14 -> 29 % of wave-cycles) and the kernel went from
+// 56.1 to 66.5 ms on the same box — profiles/r03_variant_line_pairs.txt.  Two F6 operands, the parked product and the operand sums
+// do not fit 256 registers, and this kernel's LDS holds the line stage.)
 template <class X, class Src> GPBC_INLINE F6 miller_accumulate_pair(const X &x, Src &&next) {
     // the accumulator stays positive-normalised throughout (PN forms: every step ends in a normalisation), so the F6 products inside
     // run in the subtractive Karatsuba form with no operand normalisations

@@ -75,10 +75,21 @@ for trial in range(24):
     if int(o2[-1]) == 0:
         continue
     assert (bn254.multi_pair(P[ii], Q[ii], o2) == oracle_lib.multi_pair(P[ii], Q[ii], o2, threads=threads)).all(), ("small multi-pairing", trial)
+# ... and calls whose segments are long enough to be folded over 8 / 16 wavefronts first (k_segment_fold_wide): up to 2 048 pairs per call
+for trial in range(16):
+    ks = int(rng.integers(1, 9))
+    cuts = np.sort(rng.integers(0, 2049, size=ks - 1)) if ks > 1 else np.zeros(0, dtype=np.int64)
+    o2 = np.concatenate([[0], cuts, [int(rng.integers(max(int(cuts[-1]) if ks > 1 else 1, 1), 2049))]]).astype(np.uint64)
+    ii = rng.integers(0, n, size=int(o2[-1]))
+    assert (bn254.multi_pair(P[ii], Q[ii], o2) == oracle_lib.multi_pair(P[ii], Q[ii], o2, threads=threads)).all(), ("folded multi-pairing", trial, o2)
 print("multi-pairings ok  (%d segments, %d pairs, %.1f s)" % (len(lens), m, time.time() - t0), flush=True)
 t0 = time.time()
 ke = scal(4096, full=True)
 assert (bn254.gt_exp(gt[:4096], ke) == oracle_lib.gt_exp(gt[:4096], ke, threads=threads)).all(), "GT exp"
+for lo_ in range(0, 4096, 1500):                              # the same in calls of at most 2 048 elements: one element per wavefront (k_gt_exp_wide)
+    hi_ = min(4096, lo_ + 1500)
+    kk = ke.reshape(-1, 32)[lo_:hi_].reshape(-1)
+    assert (bn254.gt_exp(gt[lo_:hi_], kk) == oracle_lib.gt_exp(gt[lo_:hi_], kk, threads=threads)).all(), "GT exp, latency form"
 assert (bn254.gt_mul(gt[:4096], gt[4096:8192]) == oracle_lib.gt_mul(gt[:4096], gt[4096:8192])).all(), "GT mul"
 fb = bn254.FixedBase(P[:16])
 ks = scal(16 * 512, full=True)

@@ -562,6 +562,37 @@ def main():
             for _ in range(3):
                 bn254.g1_scalar_mul(Ps[:1], ksm)
             lat["g1_scalar_mul_1"] = 1e3 * (time.perf_counter() - t1) / 3
+            # one BSW07-sized product (513 pairs, one final exponentiation) and one GT.Exp: the reference makes both one call at a time
+            seg513 = np.array([0, 513], dtype=np.uint64)
+            g513 = bn254.multi_pair(Ps[:513], Qs[:513], seg513)
+            t1 = time.perf_counter()
+            for _ in range(3):
+                bn254.multi_pair(Ps[:513], Qs[:513], seg513)
+            lat["multi_pair_1x513"] = 1e3 * (time.perf_counter() - t1) / 3
+            gt1 = gt[:1].cpu().numpy()
+            e1 = bn254.gt_exp(gt1, ksm)
+            t1 = time.perf_counter()
+            for _ in range(3):
+                bn254.gt_exp(gt1, ksm)
+            lat["gt_exp_1"] = 1e3 * (time.perf_counter() - t1) / 3
+            # the same single calls on ONE host core through the C restatement (the cpu_baseline's port, bit-compared)
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle_lib
+            oracle_lib.build()
+            cpu = {}
+            for name, fn, want in (("pair_batch_1", lambda: oracle_lib.pair_batch(Ps[:1], Qs[:1], threads=1), gt[:1].cpu().numpy()),
+                                   ("pairing_check_2_pairs", lambda: oracle_lib.multi_pair(Ps[:2], Qs[:2], np.array([0, 2], dtype=np.uint64), threads=1), None),
+                                   ("multi_pair_1x513", lambda: oracle_lib.multi_pair(Ps[:513], Qs[:513], seg513, threads=1), g513),
+                                   ("gt_exp_1", lambda: oracle_lib.gt_exp(gt1, ksm, threads=1), e1)):
+                got = fn()
+                reps = 1 if name == "multi_pair_1x513" else 5
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                cpu[name] = 1e3 * (time.perf_counter() - t1) / reps
+                if want is not None and not (np.asarray(got).reshape(-1) == np.asarray(want).reshape(-1)).all():
+                    raise SystemExit("PARITY FAILURE: single call %s differs from the oracle" % name)
+            lat["one_host_core_port"] = cpu
             result["call_latency_ms"] = lat
         except Exception as exc:                          # noqa: BLE001
             result["call_latency_ms"] = {"error": repr(exc)}

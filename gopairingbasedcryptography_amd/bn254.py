@@ -71,6 +71,9 @@ def release_workspaces():
 
 def shutdown():
     global _slots
+    for t in list(_gen_tables.values()):
+        t.close()
+    _gen_tables.clear()
     _lib.check(_lib.load().gpbc_shutdown())
     _slots = None
 
@@ -372,13 +375,31 @@ def g2_scalar_mul(bases, scalars, out=None):
     return _scalar_mul(G2_BYTES, lib.gpbc_g2_scalar_mul_batch, lib.gpbc_g2_scalar_mul_batch_dev, bases, scalars, out)
 
 
+_gen_tables = {}
+
+
+def _scalar_mul_base(g2, scalars):
+    """Small host-side calls go through fixed-base window tables of the generator (built on the first call, kept until shutdown():
+    32 mixed additions per multiplication instead of the variable-base kernel's doublings — what include/gpbc_bn254.hpp and the Go
+    shim do); large batches and device tensors take the shared-base form of the variable-base kernel, which builds its own table."""
+    k = scalars_to_bytes(scalars)
+    if not _is_torch(k):
+        k = _np(k, SCALAR_BYTES)
+    if _is_torch(k) or k.size // SCALAR_BYTES >= 16384:
+        return (g2_scalar_mul if g2 else g1_scalar_mul)(generators()[1 if g2 else 0], k)
+    _ensure_init()
+    if g2 not in _gen_tables:
+        _gen_tables[g2] = FixedBase(generators()[1 if g2 else 0], g2=g2)
+    return _gen_tables[g2].mul(k)
+
+
 def g1_scalar_mul_base(scalars):
     """ScalarMultiplicationBase: [s]g1."""
-    return g1_scalar_mul(generators()[0], scalars)
+    return _scalar_mul_base(False, scalars)
 
 
 def g2_scalar_mul_base(scalars):
-    return g2_scalar_mul(generators()[1], scalars)
+    return _scalar_mul_base(True, scalars)
 
 
 def _sum(width, is_g2, host_fn, dev_fn, pts):

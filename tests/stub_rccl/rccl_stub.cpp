@@ -18,6 +18,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -123,7 +124,15 @@ static void *map_file(const std::string &name, size_t bytes, bool create) {
     close(fd);
     return p == MAP_FAILED ? nullptr : p;
 }
-static void spin_until(std::atomic<unsigned long> &c, unsigned long target) { while (c.load(std::memory_order_acquire) < target) usleep(50); }
+// a rank that never arrives (its process died) must not hang the others: two minutes, then the collective fails
+static bool spin_until(std::atomic<unsigned long> &c, unsigned long target) {
+    const auto t0 = std::chrono::steady_clock::now();
+    while (c.load(std::memory_order_acquire) < target) {
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) return false;
+        usleep(50);
+    }
+    return true;
+}
 // one rank of a multi-process job: all-gather through shared memory
 static ncclResult_t remote_allgather(Remote &r, const void *send, void *recv, size_t bytes, hipStream_t stream) {
     if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;
@@ -136,7 +145,7 @@ static ncclResult_t remote_allgather(Remote &r, const void *send, void *recv, si
     }
     r.ctl->bytes[r.rank].store(bytes, std::memory_order_release);
     r.ctl->arrive.fetch_add(1, std::memory_order_acq_rel);
-    spin_until(r.ctl->arrive, done);
+    if (!spin_until(r.ctl->arrive, done)) return ncclSystemError;
     ncclResult_t rc = ncclSuccess;
     for (int q = 0; q < r.nranks && rc == ncclSuccess; q++) {
         if (r.ctl->bytes[q].load(std::memory_order_acquire) != bytes) { rc = ncclInvalidArgument; break; }
@@ -147,7 +156,7 @@ static ncclResult_t remote_allgather(Remote &r, const void *send, void *recv, si
         munmap(theirs, bytes);
     }
     r.ctl->leave.fetch_add(1, std::memory_order_acq_rel);       // nobody overwrites its file before everybody has read it
-    spin_until(r.ctl->leave, done);
+    if (!spin_until(r.ctl->leave, done) && rc == ncclSuccess) rc = ncclSystemError;
     r.round++;
     return rc;
 }

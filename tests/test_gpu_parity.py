@@ -359,6 +359,18 @@ def test_point_sums(eng, oracle, synth):
     assert not eng.g1_sum(np.zeros(0, dtype=np.uint8)).any()
 
 
+def test_scalar_mul_base_through_generator_tables(eng, oracle):
+    """ScalarMultiplicationBase for small host calls runs on fixed-base tables of the generators (as the C++ and Go host sides do):
+    same bytes as the variable-base kernel on the generator and as the oracle, zero and r - 1 and a 256-bit pattern included."""
+    g1, g2 = eng.generators()
+    ks = [0, 1, 2, o.R - 1] + [o.bench_scalar("base", i) for i in range(28)]
+    kb = eng.scalars_to_bytes(ks)
+    for base, mul_base, mul, omul in ((g1, eng.g1_scalar_mul_base, eng.g1_scalar_mul, oracle.g1_scalar_mul), (g2, eng.g2_scalar_mul_base, eng.g2_scalar_mul, oracle.g2_scalar_mul)):
+        got = mul_base(ks)
+        assert (got == mul(base, kb)).all() and (np.asarray(got).reshape(-1) == np.asarray(omul(base, kb)).reshape(-1)).all()
+        assert (mul_base([ks[5]]) == got[5:6]).all()
+
+
 def test_gt_ops_golden(eng):
     g = load_golden("gt_ops.json")
     out = eng.gt_exp(cat([c["x"] for c in g["exp"]]), cat([c["k"] for c in g["exp"]]))

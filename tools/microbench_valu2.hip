@@ -88,6 +88,23 @@ static void run(int waves_per_simd, u64 *dout, int ncu) {
     printf("%-32s waves/SIMD=%d  %8.3f ms   %.2f cycles per wave-instruction per SIMD\n", NAME[OP], waves_per_simd, best, best * 1e-3 * 2.4e9 / instrs);
     fflush(stdout);
 }
+// the same instruction in fewer independent chains per wave (1 = every MAD waits for the one before it)
+template <int OP, int CH>
+static void run_chains(int waves_per_simd, u64 *dout, int ncu) {
+    const int iters = 2048;
+    dim3 block(256), grid(ncu * waves_per_simd);
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    bench_kernel<OP, CH><<<grid, block>>>(dout, 16, 3, 5, 0x1fffffff); CHECK(hipDeviceSynchronize());
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; rep++) {
+        CHECK(hipEventRecord(e0)); bench_kernel<OP, CH><<<grid, block>>>(dout, iters, 3, 5, 0x1fffffff); CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+    }
+    double instrs = (double)iters * 8 * CH * INSTR[OP] * waves_per_simd;
+    printf("%-22s %d chain(s) per wave  waves/SIMD=%d  %8.3f ms   %.2f cycles per wave-instruction per SIMD\n", NAME[OP], CH, waves_per_simd, best, best * 1e-3 * 2.4e9 / instrs);
+    fflush(stdout);
+}
 template <int OP> static void sweep(u64 *dout, int ncu) { run<OP>(1, dout, ncu); run<OP>(2, dout, ncu); run<OP>(4, dout, ncu); }
 template <int OP> static void all(u64 *dout, int ncu) { sweep<OP>(dout, ncu); if constexpr (OP + 1 < N_OPS) all<OP + 1>(dout, ncu); }
 
@@ -96,5 +113,7 @@ int main() {
     printf("device %s  arch %s  CUs %d  (cycles at the nominal 2.4 GHz)\n", prop.name, prop.gcnArchName, prop.multiProcessorCount);
     u64 *dout; CHECK(hipMalloc(&dout, 8));
     all<0>(dout, prop.multiProcessorCount);
+    for (int w : {1, 2, 4}) { run_chains<MAD_I64, 1>(w, dout, prop.multiProcessorCount); run_chains<MAD_I64, 2>(w, dout, prop.multiProcessorCount); run_chains<MAD_I64, 4>(w, dout, prop.multiProcessorCount); }
+    for (int w : {1, 2, 4}) { run_chains<MAD_PLUS_ADD, 1>(w, dout, prop.multiProcessorCount); run_chains<MAD_PLUS_ADD, 2>(w, dout, prop.multiProcessorCount); }
     return 0;
 }

@@ -201,9 +201,14 @@ template <class X> GPBC_NOINLINE F6 f12p_exp256(const X &x, const F6 &b, const u
     cur = b;
     f6_row_store(tab + GT_EXP_ROW_DWORDS, cur);
     for (int i = 2; i < 16; i++) { cur = f12p_mul(x, cur, b); f6_row_store(tab + i * GT_EXP_ROW_DWORDS, cur); }
+    // a wavefront whose bases all lie in the cyclotomic subgroup (pairing values: what the reference's call sites raise) squares by
+    // Granger-Scott, 3.5 k instead of 6 k instructions per squaring; one base outside it (a Miller value, a random Fp12 element —
+    // gnark's Exp takes those too) and the whole wavefront squares generically, so that no lane pair waits for another's path
+    const bool cyclotomic = x.all(f12p_is_cyclotomic(x, b));
     F6 r = f6_row_load(tab + ((k[7] >> 28) & 15) * GT_EXP_ROW_DWORDS);
     for (int w = 62; w >= 0; w--) {
-        for (int s = 0; s < 4; s++) r = f6_reduce(f12p_sqr(x, r));
+        if (cyclotomic) { bool flipped = false; r = f12p_cyclo_sqr_run(x, r, 4, flipped); }
+        else for (int s = 0; s < 4; s++) r = f6_reduce(f12p_sqr(x, r));
         int d = (k[w >> 3] >> (4 * (w & 7))) & 15;
         r = f12p_mul(x, r, f6_row_load(tab + d * GT_EXP_ROW_DWORDS));      // d = 0 multiplies by one: no divergence
     }

@@ -63,6 +63,14 @@ struct PairDpp {
         for (int i = 0; i < NL; i++) r.v[i] = a.v[i] + sw(b.v[i]);
         return r;
     }
+    // true when `c` holds on every active lane of the wavefront (a uniform value: branches on it do not diverge)
+    __device__ __forceinline__ static bool all(bool c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return __builtin_amdgcn_ballot_w64(!c) == 0;
+#else
+        return c;
+#endif
+    }
 };
 #endif
 // policy helpers on the tower types; the host policy of tools/bounds_check.cpp provides the same two Fe primitives
@@ -320,6 +328,18 @@ template <class X> GPBC_INLINE F6 f12p_frob(const X &x, const F6 &h, int j) {
         g[i] = (i == 0) ? f2_sel(x.odd, prod, g[i]) : prod;
     }
     return F6{g[0], g[1], g[2]};
+}
+
+// Is the pair's value in the cyclotomic subgroup, x^(p^4 - p^2 + 1) = 1 ?  Tested as x^(p^4) x == x^(p^2): two Frobenius maps and one
+// product.  The same answer on both lanes.  (Granger-Scott squarings are right exactly there, and so is conj = inverse; every pairing
+// value is in it, a Miller value or a random Fp12 element is not.)
+template <class X> GPBC_INLINE bool f12p_is_cyclotomic(const X &x, const F6 &h) {
+    F6 t2 = f12p_frob(x, h, 2);
+    F6 t4 = f12p_frob(x, f6_reduce(f6_norm(t2)), 2);
+    F6 d = f6_norm(f6_sub(f12p_mul(x, f6_reduce(f6_norm(t4)), h), t2));
+    const bool mine = f2_is_zero(d.b0) && f2_is_zero(d.b1) && f2_is_zero(d.b2);
+    const Fe flag = x.swap(fe_sel(mine, fe_one(), fe_zero()));
+    return mine && !fe_is_zero(flag);
 }
 
 // 1 / (c0 + c1 w) = (c0 - c1 w) / (c0^2 - v c1^2)

@@ -344,8 +344,27 @@ template <class M> GPBC_INLINE void wide_final_exp(M &m) {
 // ---- GT.Exp for the latency path: value 0 <- x^k for a 256-bit plain exponent (k = 0 -> one), x any Fp12 element (gnark's Exp is the
 // generic square-and-multiply, and callers hand it values outside the cyclotomic subgroup too).  Three-bit windows from the top over
 // the table x^1 .. x^7 in values 1..7; the exponent is the same for every lane of the wavefront, so the digit branches are uniform.
+// Is value `a` in the cyclotomic subgroup (a^(p^4) a == a^(p^2), see f12p_is_cyclotomic)?  t2, t4: two scratch values.  The same
+// answer on every lane.
+template <class M> GPBC_INLINE bool wide_is_cyclotomic(M &m, int a, int t2, int t4) {
+    wide_frob(m, t2, a, 2);
+    wide_frob(m, t4, t2, 2);
+    wide_mul(m, t4, t4, a);
+    m.run(6, [&](int c) {
+        const F2 d = f2_norm(f2_sub(m.ld(t4 + c), m.ld(t2 + c)));
+        m.st(W_G + c, f2_sel(f2_is_zero(d), f2_one(), f2_zero()));
+    });
+    bool ok = true;
+    for (int c = 0; c < 6; c++) ok = ok && !f2_is_zero(m.ld(W_G + c));
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GPBC_BOUNDS)
+    ok = __builtin_amdgcn_readfirstlane((int)ok) != 0;       // every lane read the same six flags: say so to the compiler
+#endif
+    return ok;
+}
 template <class M> GPBC_INLINE void wide_exp256(M &m, const uint32_t (&k)[8]) {
     constexpr int Z = wv(0);
+    // pairing values (what the reference raises) square by Granger-Scott: 18 half products instead of 36 products per squaring
+    const bool cyclotomic = wide_is_cyclotomic(m, wv(1), wv(8), wv(9));
     for (int e = 2; e < 8; e++) wide_mul(m, wv(e), wv(e - 1), wv(1));
     bool started = false;
     for (int w = 85; w >= 0; w--) {
@@ -353,7 +372,7 @@ template <class M> GPBC_INLINE void wide_exp256(M &m, const uint32_t (&k)[8]) {
         uint32_t d = k[word] >> sh;
         if (sh > 29 && word < 7) d |= k[word + 1] << (32 - sh);
         d &= 7u;
-        if (started) for (int q = 0; q < 3; q++) wide_mul(m, Z, Z, Z);
+        if (started) for (int q = 0; q < 3; q++) { if (cyclotomic) wide_cyclo_sqr(m, Z, Z); else wide_mul(m, Z, Z, Z); }
         if (d) {
             if (started) wide_mul(m, Z, Z, wv((int)d));
             else { wide_copy(m, Z, wv((int)d)); started = true; }

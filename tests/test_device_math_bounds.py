@@ -20,8 +20,8 @@ SO = os.path.join(ROOT, "tools", "libgpbc_bounds.so")
 @pytest.fixture(scope="module")
 def hc():
     src = os.path.join(ROOT, "tools", "bounds_check.cpp")
-    hdrs = [os.path.join(ROOT, "gopairingbasedcryptography_amd", "csrc", f)
-            for f in ("fe29.hip.hpp", "tower29.hip.hpp", "tower29_pair.hip.hpp", "curve29.hip.hpp", "pairing29.hip.hpp", "pairing29_pair.hip.hpp", "wire29.hip.hpp", "msm29.hip.hpp")]
+    import glob
+    hdrs = glob.glob(os.path.join(ROOT, "gopairingbasedcryptography_amd", "csrc", "*.hpp"))      # every header the harness can include
     if not os.path.exists(SO) or any(os.path.getmtime(f) > os.path.getmtime(SO) for f in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-pthread", "-std=c++17", "-DGPBC_BOUNDS", "-shared", "-fPIC", "-o", SO, src])
     return ctypes.CDLL(SO)

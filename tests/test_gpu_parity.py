@@ -400,10 +400,15 @@ def test_gt_exp_vs_oracle(eng, oracle, synth):
     for i, e in enumerate((0, 1, 2, 7, 8, o.R - 1, o.R, 1 << 255, (1 << 256) - 1)):
         k[i] = k[20 + i] = np.frombuffer(e.to_bytes(32, "little"), dtype=np.uint8)
     want = oracle.gt_exp(gt, k.reshape(-1), threads=8)
+    # wavefronts (32 elements) of pairing values only square by Granger-Scott, any other element in a wavefront sends it down the
+    # general path: `gt` mixes both in its first wavefront, `gt_c` is cyclotomic throughout
+    gt_c = eng.pair_batch(P, Q)
+    want_c = oracle.gt_exp(gt_c, k.reshape(-1), threads=8)
     try:
         for knob in (0, 2048):
             _lib.check(lib.gpbc_set_latency_path(knob))
             assert (eng.gt_exp(gt, k.reshape(-1)) == want).all(), knob
+            assert (eng.gt_exp(gt_c, k.reshape(-1)) == want_c).all(), knob
             assert (eng.gt_exp(gt[:1], k[:1].reshape(-1)) == want[:1]).all() and (eng.gt_exp(gt[3:4], k[3:4].reshape(-1)) == want[3:4]).all(), knob
     finally:
         lib.gpbc_set_latency_path(2048)

@@ -47,6 +47,7 @@ struct PairHost {
     F6 swap(const F6 &a) const { return rv->exchange<F6>(odd, a); }
     Fe sgn(const Fe &a) const { return odd ? a : fe_neg(a); }                       // device: one multiplication by the lane's +-1
     Fe add_swap(const Fe &a, const Fe &b) const { return fe_add(a, swap(b)); }       // device: v_add_u32_dpp
+    static bool all(bool c) { return c; }                                            // device: the whole wavefront must agree
 };
 static std::mutex g_stats_mu;
 static BoundStats g_stats_total;

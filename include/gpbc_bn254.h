@@ -144,8 +144,11 @@ int gpbc_set_pipelined_miller(int on);
  * signature/bls01_signature/bls_signature.go:81, ...); in the throughput kernels one pairing is a chain of ~2 M dependent
  * instructions on one lane pair — ~6 ms per call whatever the batch size.  Calls of at most `max_pairs` Miller loops / final
  * exponentiations (default 2048: one wave per SIMD pair of the chip) run ONE PAIRING PER WAVEFRONT instead, the 64 lanes working
- * on the F2 products inside it (csrc/wide29.hip.hpp): same bits, about a fifth of the latency (1.2 ms per call).  0 switches the path off (tests
- * compare the two forms). */
+ * on the F2 products inside it (csrc/wide29.hip.hpp): same bits, about a fifth of the latency (1.2 ms per call).  The same limit
+ * sends GT.Exp calls of at most `max_pairs` elements down a one-element-per-wavefront kernel (0.8 ms instead of 5 ms for one
+ * new(GT).Exp, access/tree/access_tree_node.go:114), and multi-pairing calls of at most `max_pairs` pairs multiply the Miller
+ * values of long segments on 8 or 16 wavefronts each (one 513-pair Pair: 1.5 ms).  0 switches the path off (tests compare the
+ * two forms). */
 int gpbc_set_latency_path(long max_pairs);
 /* Fail-closed self-check of the host-table multi-pairings (gpbc_multi_pair, gpbc_pairing_check, gpbc_multi_pair_hostseg_dev): the
  * segment / chunk tables travel through library-owned pinned memory, the kernels echo the pairs they consumed per segment, and

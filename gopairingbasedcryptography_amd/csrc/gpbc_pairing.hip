@@ -516,10 +516,10 @@ GPBC_KERNEL k_gt_binary(const uint8_t *__restrict__ a, const uint8_t *__restrict
     if (i >= n) return;
     F12 x, y, z;
     f12_load(x, a + i * GPBC_GT_BYTES);
-    if (op == 2) z = f12_inv(x);
+    if (op == 2) z = f12_inv_gt(x, PairDpp::all);
     else {
         f12_load(y, b + i * GPBC_GT_BYTES);
-        if (op == 1) y = f12_inv(y);
+        if (op == 1) y = f12_inv_gt(y, PairDpp::all);
         z = f12_mul(x, y);
     }
     f12_store(out + i * GPBC_GT_BYTES, z);

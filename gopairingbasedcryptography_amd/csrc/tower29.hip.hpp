@@ -266,6 +266,21 @@ GPBC_INLINE F12 f12_inv(const F12 &x) {
     F6 d = f6_inv(f6_norm(f6_sub(f6_sqr(x.c0), t1)));
     return F12{f6_mul(x.c0, d), f6_neg(f6_mul(x.c1, d))};
 }
+// 1 / y = conj(y) / N(y) with the norm N(y) = c0^2 - v c1^2 in Fp6.  What the reference divides by is a pairing value (GT.Div of a
+// ciphertext component by a pairing product, bibe/afp25_bibe/afp25_bibe.go:408-413, cpabe/bsw07/bsw07_cpabe.go:189-190), and those have
+// norm one: when every element of the wavefront does (`all`: the agreement of the active lanes), the Fp6 inversion and the two Fp6
+// products are skipped (40 k -> 8 k instructions); any other element in the wavefront and all of it takes the general path — the
+// same field element either way.
+GPBC_INLINE bool f6_is_one(const F6 &v) {
+    const F2 d = f2_norm(f2_sub(v.b0, f2_one()));
+    return f2_is_zero(d) && f2_is_zero(v.b1) && f2_is_zero(v.b2);
+}
+template <class All> GPBC_INLINE F12 f12_inv_gt(const F12 &y, All &&all) {
+    const F6 nrm = f6_norm(f6_sub(f6_sqr(y.c0), f6_mul_v(f6_sqr(y.c1))));
+    if (all(f6_is_one(nrm))) return f12_conj(y);
+    const F6 d = f6_inv(nrm);
+    return F12{f6_mul(y.c0, d), f6_neg(f6_mul(y.c1, d))};
+}
 // x^(p^j), j = 1..3: coefficient of w^k -> (conj if j odd)(c_k) * gamma_j[k]; w-basis order C0.B0,C1.B0,C0.B1,C1.B1,C0.B2,C1.B2
 GPBC_INLINE F12 f12_frob(const F12 &x, int j) {
     const bool odd = j & 1;

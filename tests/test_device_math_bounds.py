@@ -70,9 +70,18 @@ def test_field_and_gt_ops_under_bounds(hc, oracle):
     hc.hc_gt_sqr(vp(A), ctypes.c_size_t(len(g)), vp(sq), ctypes.c_int(0))
     cs = np.zeros((len(g), 384), dtype=np.uint8)
     hc.hc_gt_sqr(vp(A), ctypes.c_size_t(len(g)), vp(cs), ctypes.c_int(1))
+    dv = np.zeros((len(g), 384), dtype=np.uint8)
+    hc.hc_gt_div(vp(A), vp(B), ctypes.c_size_t(len(g)), vp(dv))            # pairing values: norm one, the conjugate path of k_gt_binary
     for i, c in enumerate(g):
-        assert m[i].tobytes().hex() == c["mul"] and inv[i].tobytes().hex() == c["inv_a"]
+        assert m[i].tobytes().hex() == c["mul"] and inv[i].tobytes().hex() == c["inv_a"] and dv[i].tobytes().hex() == c["div"]
     assert (sq == oracle.gt_mul(A, A)).all() and (cs == sq).all()
+    # ... and divisors of norm other than one (random Fp12 elements): the general path
+    rnd = np.frombuffer(b"".join((int.from_bytes(rng.bytes(32), "little") % o.P).to_bytes(32, "little") for _ in range(12 * 4)), dtype=np.uint8)
+    Bm = oracle.fp_mul(rnd, np.frombuffer(b"".join((pow(2, 512, o.P)).to_bytes(32, "little") for _ in range(48)), dtype=np.uint8)).reshape(4, 384).copy()   # to Montgomery form
+    dv2 = np.zeros((4, 384), dtype=np.uint8)
+    A4 = A.reshape(-1, 384)[:4].copy()
+    hc.hc_gt_div(vp(A4), vp(Bm), ctypes.c_size_t(4), vp(dv2))
+    assert (dv2 == oracle.gt_div(A4, Bm)).all()
 
 
 def test_bound_margins(hc):

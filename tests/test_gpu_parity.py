@@ -414,6 +414,19 @@ def test_gt_exp_vs_oracle(eng, oracle, synth):
         lib.gpbc_set_latency_path(2048)
 
 
+def test_gt_div_and_inverse_on_any_divisor(eng, oracle, synth):
+    """GT.Div / GT.Inverse take the conjugate when every divisor of a wavefront has norm one (pairing values) and the Fp6 inversion
+    otherwise: wavefronts (64 elements) of pairing values only, of Miller values only (norm not one), and mixed — against the oracle."""
+    P, Q = synth[0][:160], synth[1][:160]
+    a = eng.pair_batch(P, Q)
+    b = eng.pair_batch(P[::-1].copy(), Q)
+    b[64:128] = eng.miller_loop(P[64:128], Q[64:128])          # second wavefront: general divisors
+    b[130:140] = eng.miller_loop(P[130:140], Q[130:140])       # third: mixed
+    assert (eng.gt_div(a, b) == oracle.gt_div(a, b)).all()
+    assert (eng.gt_inverse(b) == oracle.gt_inverse(b)).all()
+    assert (eng.gt_div(a[:1], b[:1]) == oracle.gt_div(a[:1], b[:1])).all() and (eng.gt_inverse(b[64:65]) == oracle.gt_inverse(b[64:65])).all()
+
+
 def test_bilinearity_property(eng, synth):
     """e([a]P,[b]Q) == e(P,Q)^(ab) and the restructuring identities of SURVEY §8a-3, all on the GPU."""
     P, Q = synth[0][:16], synth[1][:16]

@@ -236,6 +236,13 @@ void hc_fp_legendre(const uint8_t *A, size_t n, int8_t *out) {
 void hc_gt_mul(const uint8_t *A, const uint8_t *B, size_t n, uint8_t *out) {
     for (size_t i = 0; i < n; i++) { F12 a, b; f12_load(a, A + 384 * i); f12_load(b, B + 384 * i); f12_store(out + 384 * i, f12_mul(a, b)); }
 }
+// a / b as k_gt_binary computes it (norm-one divisors: conjugate instead of the Fp6 inversion)
+void hc_gt_div(const uint8_t *A, const uint8_t *B, size_t n, uint8_t *out) {
+    for (size_t i = 0; i < n; i++) {
+        F12 a, b; f12_load(a, A + 384 * i); f12_load(b, B + 384 * i);
+        f12_store(out + 384 * i, f12_mul(a, f12_inv_gt(b, [](bool c) { return c; })));
+    }
+}
 void hc_gt_inv(const uint8_t *A, size_t n, uint8_t *out) {
     for (size_t i = 0; i < n; i++) { F12 a; f12_load(a, A + 384 * i); f12_store(out + 384 * i, f12_inv(a)); }
 }

@@ -396,6 +396,7 @@ def test_gt_exp_vs_oracle(eng, oracle, synth):
     P, Q = synth[0][:40], synth[1][:40]
     gt = eng.pair_batch(P, Q)
     gt[20:] = eng.miller_loop(P[20:], Q[20:])
+    gt[19] = 0                                                 # the zero element: 0^k = 0, 0^0 = 1 (it passes the subgroup test: 0 * 0 == 0)
     k = scalars("gtexp", 40).reshape(40, 32).copy()
     for i, e in enumerate((0, 1, 2, 7, 8, o.R - 1, o.R, 1 << 255, (1 << 256) - 1)):
         k[i] = k[20 + i] = np.frombuffer(e.to_bytes(32, "little"), dtype=np.uint8)
@@ -422,6 +423,7 @@ def test_gt_div_and_inverse_on_any_divisor(eng, oracle, synth):
     b = eng.pair_batch(P[::-1].copy(), Q)
     b[64:128] = eng.miller_loop(P[64:128], Q[64:128])          # second wavefront: general divisors
     b[130:140] = eng.miller_loop(P[130:140], Q[130:140])       # third: mixed
+    b[141] = 0                                                 # 1 / 0 = 0 (gnark's Inverse convention, the oracle's too)
     assert (eng.gt_div(a, b) == oracle.gt_div(a, b)).all()
     assert (eng.gt_inverse(b) == oracle.gt_inverse(b)).all()
     assert (eng.gt_div(a[:1], b[:1]) == oracle.gt_div(a[:1], b[:1])).all() and (eng.gt_inverse(b[64:65]) == oracle.gt_inverse(b[64:65])).all()

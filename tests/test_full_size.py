@@ -61,6 +61,24 @@ def test_config1_pairs_2_20(eng, oracle, dev):
     one = np.frombuffer(o.gt_to_bytes(o.F12_ONE), dtype=np.uint8)
     prod = eng.gt_mul(gt, eng.gt_inverse(gt))
     assert bool((prod == d(one)).all()) and not bool((gt == d(one)).all(dim=1).any())
+    # GT.Exp over the whole batch (pairing values: the Granger-Scott path of k_gt_exp): x^a x^b == x^(a+b) with two 254-bit exponents
+    # per element, oracle on a few of them; and the same identity on 2^16 Miller values (outside the cyclotomic subgroup: general path)
+    ka, kb = w.bench_scalars("ea", 0, n).reshape(n, 32), w.bench_scalars("eb", 0, n).reshape(n, 32)
+    la, lb = ka.copy().view("<u8").astype(object), kb.copy().view("<u8").astype(object)
+    carry, limbs = np.zeros(n, dtype=object), []
+    for j in range(4):
+        t = la[:, j] + lb[:, j] + carry
+        limbs.append((t & 0xFFFFFFFFFFFFFFFF).astype(np.uint64)); carry = t >> 64
+    ksum = np.ascontiguousarray(np.stack(limbs, axis=1)).view(np.uint8).reshape(n, 32)
+    xa, xb, xs = eng.gt_exp(gt, d(ka)), eng.gt_exp(gt, d(kb)), eng.gt_exp(gt, d(ksum))
+    assert bool((eng.gt_mul(xa, xb) == xs).all())
+    pick = np.array([0, 31, 32, 4097, n - 1])
+    assert (xs[pick].cpu().numpy() == oracle.gt_exp(gt[pick].cpu().numpy(), ksum[pick].reshape(-1), threads=5)).all()
+    m = 1 << 16
+    f = eng.miller_loop(P[:m].contiguous(), Q[:m].contiguous())
+    fa, fb, fs = eng.gt_exp(f, d(ka[:m])), eng.gt_exp(f, d(kb[:m])), eng.gt_exp(f, d(ksum[:m]))
+    assert bool((eng.gt_mul(fa, fb) == fs).all())
+    assert (fs[pick[:4]].cpu().numpy() == oracle.gt_exp(f[pick[:4]].cpu().numpy(), ksum[pick[:4]].reshape(-1), threads=4)).all()
 
 
 def test_config2_aggregate_verify_2_20(eng, oracle, dev):

@@ -128,11 +128,11 @@ template <class X> GPBC_NOINLINE void f12p_expt_to(const X &x, F6 &z, const F6 &
 template <class X> GPBC_NOINLINE void f12p_mul_to(const X &x, F6 &z, const F6 &a, const F6 &b) { z = f12p_mul(x, a, b); }
 // x^(s (p^12-1)/r) on a lane pair; operation order of final_exp29.  Eight named F6 values are the whole working set.
 template <class X> GPBC_INLINE F6 final_exp_pair(const X &x, const F6 &in) {
-    F6 r, t0, t1, t2, t3, t4, u, w;
-    u = f12p_conj(x, in); w = f12p_inv(x, in);
-    f12p_mul_to(x, t0, u, w);
-    u = f12p_frob(x, t0, 2);
-    f12p_mul_to(x, r, u, t0);
+    F6 r, t0, t1, t2, t3, t4;                                  // t3 / t4 / t1 double as the short-lived operands (one frame slot less each)
+    t3 = f12p_conj(x, in); t4 = f12p_inv(x, in);
+    f12p_mul_to(x, t0, t3, t4);
+    t3 = f12p_frob(x, t0, 2);
+    f12p_mul_to(x, r, t3, t0);
     f12p_expt_to(x, t0, r); t0 = f12p_conj(x, t0);
     t0 = f12p_cyclo_sqr<true>(x, t0);
     t1 = f12p_cyclo_sqr<true>(x, t0);
@@ -150,11 +150,11 @@ template <class X> GPBC_INLINE F6 final_exp_pair(const X &x, const F6 &in) {
     f12p_mul_to(x, t0, t2, t0);
     t2 = f12p_frob(x, t4, 2);
     f12p_mul_to(x, t0, t2, t0);
-    u = f12p_conj(x, r);
-    f12p_mul_to(x, t2, u, t3);
+    t1 = f12p_conj(x, r);
+    f12p_mul_to(x, t2, t1, t3);
     t2 = f12p_frob(x, t2, 3);
-    f12p_mul_to(x, u, t2, t0);
-    return u;
+    f12p_mul_to(x, t1, t2, t0);
+    return t1;
 }
 
 // b^k for a 256-bit k (GT.Exp: generic squarings, so any Fp12 element is handled, not only the cyclotomic subgroup;

@@ -319,7 +319,8 @@ struct WideLds {
 // side by side on two SIMDs instead of one after the other.  Both waves belong to one workgroup, so both are resident: the consumer's
 // wait always ends.
 constexpr int WIDE_MILLER_THREADS = 128;
-__global__ void __launch_bounds__(WIDE_MILLER_THREADS, 2) k_miller_wide(const uint8_t *__restrict__ P, const uint8_t *__restrict__ Q, uint8_t *__restrict__ f_out, size_t n) {
+// q_mod > 0: pair i takes Q[i % q_mod] (one G2 list shared by every segment: the small calls of the fixed-Q entry)
+__global__ void __launch_bounds__(WIDE_MILLER_THREADS, 2) k_miller_wide(const uint8_t *__restrict__ P, const uint8_t *__restrict__ Q, uint8_t *__restrict__ f_out, size_t n, size_t q_mod) {
     __shared__ w128 w_mem[W_SLOTS * 6];
     __shared__ w128 w_ring[MILLER_LINES * 3 * 6];
     __shared__ int w_lines_ready;
@@ -327,7 +328,7 @@ __global__ void __launch_bounds__(WIDE_MILLER_THREADS, 2) k_miller_wide(const ui
     if (i >= n) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const WideLds m{w_mem, lane};
-    const uint8_t *p = P + i * GPBC_G1_BYTES, *q = Q + i * GPBC_G2_BYTES;
+    const uint8_t *p = P + i * GPBC_G1_BYTES, *q = Q + (q_mod ? i % q_mod : i) * GPBC_G2_BYTES;
     if (g1_bytes_inf(p) || g2_bytes_inf(q)) {                // the same for the whole workgroup
         if (wave == 1 && lane < 6) f2_store(f_out + i * GPBC_GT_BYTES + 64 * lane, f2_sel(lane == 0, f2_one(), f2_zero()));
         return;
@@ -363,12 +364,12 @@ GPBC_KERNEL k_final_exp_wide(const uint8_t *f_in, uint8_t *gt_out, size_t n) {
 // Long segments of a latency call (one BSW07 ciphertext is 513 pairs, a BB04 identity 257): `fold` wavefronts per segment each
 // multiply one residue class of the segment's Miller values — lo + s, lo + s + fold, ... — and leave the product in place at lo + s,
 // so that the wavefront of k_segment_final_exp_wide multiplies `fold` values instead of the whole run.  Same clamping of the table.
-GPBC_KERNEL k_segment_fold_wide(uint8_t *f, const uint64_t *__restrict__ seg_off, size_t k, size_t n_vals, unsigned fold) {
+GPBC_KERNEL k_segment_fold_wide(uint8_t *f, const uint64_t *__restrict__ seg_off, size_t uniform_len, size_t k, size_t n_vals, unsigned fold) {
     __shared__ w128 w_mem[W_SLOTS * 6];
     const size_t j = blockIdx.x / fold;
     const uint64_t s = blockIdx.x % fold;
     if (j >= k) return;
-    uint64_t lo = seg_off[j], hi = seg_off[j + 1];
+    uint64_t lo = seg_off ? seg_off[j] : j * uniform_len, hi = seg_off ? seg_off[j + 1] : (j + 1) * uniform_len;   // no table: equal runs
     if (hi > n_vals) hi = n_vals;
     if (lo > hi) lo = hi;
     if (hi - lo <= s + fold) return;                        // this class holds at most one value: it stays where it is
@@ -386,13 +387,13 @@ GPBC_KERNEL k_segment_fold_wide(uint8_t *f, const uint64_t *__restrict__ seg_off
 // of the table and the same echo (first value, values consumed) as k_segment_product.
 // `fold` > 0: k_segment_fold_wide ran first with that many residue classes, so the segment's product is the product of its first
 // `fold` values.
-GPBC_KERNEL k_segment_final_exp_wide(const uint8_t *__restrict__ f, const uint64_t *__restrict__ seg_off, uint8_t *__restrict__ out, size_t k, size_t n_vals,
+GPBC_KERNEL k_segment_final_exp_wide(const uint8_t *__restrict__ f, const uint64_t *__restrict__ seg_off, size_t uniform_len, uint8_t *__restrict__ out, size_t k, size_t n_vals,
                                      uint64_t *__restrict__ echo, unsigned fold) {
     __shared__ w128 w_mem[W_SLOTS * 6];
     const size_t j = blockIdx.x;
     if (j >= k) return;
     const WideLds m{w_mem, (int)threadIdx.x};
-    uint64_t lo = seg_off[j], hi = seg_off[j + 1];
+    uint64_t lo = seg_off ? seg_off[j] : j * uniform_len, hi = seg_off ? seg_off[j + 1] : (j + 1) * uniform_len;
     if (hi > n_vals) hi = n_vals;
     if (lo > hi) lo = hi;
     const uint64_t end = (fold && hi - lo > fold) ? lo + fold : hi;
@@ -424,8 +425,32 @@ GPBC_KERNEL k_final_exp(const uint8_t *f_in, uint8_t *gt_out, size_t n) {
 // With `seen` null the values are single Miller values and the echo is the table entry as used; with `seen` the values are chunk
 // products and the echo is folded from the bounds k_miller_accumulate_chunks recorded per chunk (count ~0 if the chunks of the
 // segment were not contiguous).  The host-table entries compare the echo with the table they copied (multi_pair_core).
+// Long segments (one bn254.Pair of a few hundred pairs: a BSW07 or BB04 call) would leave that thread a chain of hundreds of Fp12
+// products at a lone lane's pace — 21 ms for 513 values, 5 s for 10^5.  k_segment_fold runs first, in passes: `fold` lane pairs per
+// segment each multiply one residue class of the segment's first `limit` values (0 = all of them) — lo + s, lo + s + fold, ... — in
+// place at lo + s, so that the next pass, and at the end this kernel, see at most `fold` values (segment_fold_passes).  Segments come
+// from the table (clamped as below) or, with seg_off null, are the runs of `uniform_len` values of the fixed-Q form.
+GPBC_KERNEL k_segment_fold(uint8_t *f, const uint64_t *__restrict__ seg_off, size_t uniform_len, size_t k, size_t n_vals, unsigned fold, uint64_t limit) {
+    const size_t lane = (size_t)blockIdx.x * BLOCK + threadIdx.x, t = lane >> 1;
+    const size_t j = t / fold;
+    const uint64_t s = t % fold;
+    if (j >= k) return;
+    PairDpp x{(bool)(lane & 1)};
+    uint64_t lo = seg_off ? seg_off[j] : j * uniform_len, hi = seg_off ? seg_off[j + 1] : (j + 1) * uniform_len;
+    if (hi > n_vals) hi = n_vals;
+    if (lo > hi) lo = hi;
+    if (limit && hi - lo > limit) hi = lo + limit;
+    if (hi - lo <= s + fold) return;                          // at most one value in this class (both lanes of the pair agree)
+    const size_t half = x.odd ? 192 : 0;
+    F6 acc = f6_load(f + (lo + s) * GPBC_GT_BYTES + half);
+    for (uint64_t i = lo + s + fold; i < hi; i += fold) {
+        const F6 v = f6_load(f + i * GPBC_GT_BYTES + half);
+        f12p_mul_to(x, acc, acc, v);
+    }
+    f6_store(f + (lo + s) * GPBC_GT_BYTES + half, acc);
+}
 GPBC_KERNEL k_segment_product(const uint8_t *__restrict__ f, const uint64_t *__restrict__ seg_off, uint8_t *__restrict__ out, size_t k, size_t n_vals,
-                              const uint64_t *__restrict__ seen, uint64_t *__restrict__ echo) {
+                              const uint64_t *__restrict__ seen, uint64_t *__restrict__ echo, uint64_t limit) {
     size_t j = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (j >= k) return;
     F12 acc = f12_one(), t;
@@ -440,7 +465,8 @@ GPBC_KERNEL k_segment_product(const uint8_t *__restrict__ f, const uint64_t *__r
         for (uint64_t i = lo; i < hi; i++) { contiguous = contiguous && seen[2 * i] == expect && seen[2 * i + 1] >= expect; expect = seen[2 * i + 1]; }
         count = contiguous ? expect - first : ~0ull;
     }
-    for (uint64_t i = lo; i < hi; i++) {
+    const uint64_t end = (limit && hi - lo > limit) ? lo + limit : hi;        // k_segment_fold left the product in the first `limit` values
+    for (uint64_t i = lo; i < end; i++) {
         f12_load(t, f + i * GPBC_GT_BYTES);
         acc = f12_mul(acc, t);
     }
@@ -449,11 +475,12 @@ GPBC_KERNEL k_segment_product(const uint8_t *__restrict__ f, const uint64_t *__r
 }
 
 // the same product over equal runs of n_c values per output (fixed-Q multi-pairing: no table needed)
-GPBC_KERNEL k_chunk_product(const uint8_t *__restrict__ f, uint8_t *__restrict__ out, size_t k, size_t n_c) {
+GPBC_KERNEL k_chunk_product(const uint8_t *__restrict__ f, uint8_t *__restrict__ out, size_t k, size_t n_c, uint64_t limit) {
     size_t j = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (j >= k) return;
     F12 acc = f12_one(), t;
-    for (size_t i = j * n_c; i < (j + 1) * n_c; i++) {
+    const size_t end = (limit && n_c > limit) ? j * n_c + limit : (j + 1) * n_c;
+    for (size_t i = j * n_c; i < end; i++) {
         f12_load(t, f + i * GPBC_GT_BYTES);
         acc = f12_mul(acc, t);
     }
@@ -547,7 +574,7 @@ int gpbc_miller_loop_dev(const void *dP, const void *dQ, size_t n, void *d_f_out
     hipStream_t st = (hipStream_t)stream;
     size_t chunk = n < MILLER_CHUNK ? n : MILLER_CHUNK;
     if (n <= g_wide_max.load()) {
-        k_miller_wide<<<(unsigned)n, WIDE_MILLER_THREADS, 0, st>>>((const uint8_t *)dP, (const uint8_t *)dQ, (uint8_t *)d_f_out, n);
+        k_miller_wide<<<(unsigned)n, WIDE_MILLER_THREADS, 0, st>>>((const uint8_t *)dP, (const uint8_t *)dQ, (uint8_t *)d_f_out, n, 0);
         TRY(check_launch("k_miller_wide"));
         profile_mark("k_miller_wide", st);
         return GPBC_OK;
@@ -601,6 +628,39 @@ int gpbc_pair_batch_dev(const void *dP, const void *dQ, size_t n, void *d_gt_out
     return gpbc_final_exp_dev(d_gt_out, n, d_gt_out, stream);      // each lane rewrites its own 384 B
 }
 size_t gpbc_multi_pair_workspace_bytes(size_t n_pairs, size_t k) { (void)k; return n_pairs * GPBC_GT_BYTES; }
+// The passes of k_segment_fold that leave at most 8 values per segment for the one-thread product (`limit_out`; 0 = no pass ran).
+// Fold widths 4096 / 512 / 64 / 8, starting at the smallest one whose classes hold about 8 values for an AVERAGE segment — a table in
+// device memory is not known to the host, and a skewed one only makes its long segments' chains longer, never wrong.
+static int segment_fold_passes(uint8_t *vals, const uint64_t *d_seg_off, size_t uniform_len, size_t k, size_t n_vals, hipStream_t st, uint64_t *limit_out) {
+    *limit_out = 0;
+    const size_t avg = n_vals / k;
+    if (avg <= 8) return GPBC_OK;
+    unsigned fold = 8;
+    while (fold < 4096 && (size_t)fold * 8 < avg) fold *= 8;
+    uint64_t limit = 0;
+    for (;; fold /= 8) {
+        k_segment_fold<<<grid_for(2 * k * fold), BLOCK, 0, st>>>(vals, d_seg_off, uniform_len, k, n_vals, fold, limit);
+        TRY(check_launch("k_segment_fold"));
+        profile_mark("k_segment_fold", st);
+        limit = fold;
+        if (fold == 8) break;
+    }
+    *limit_out = 8;
+    return GPBC_OK;
+}
+// latency path, after the Miller loop: the values of each segment (table, or equal runs of `uniform_len`) multiplied and exponentiated
+static int segments_wide(uint8_t *vals, const uint64_t *d_seg_off, size_t uniform_len, size_t k, size_t n_vals, uint8_t *d_gt_out, uint64_t *d_echo, hipStream_t st) {
+    const unsigned fold = n_vals >= 128 * k ? 16u : n_vals >= 32 * k ? 8u : 0u;
+    if (fold) {
+        k_segment_fold_wide<<<(unsigned)(k * fold), BLOCK, 0, st>>>(vals, d_seg_off, uniform_len, k, n_vals, fold);
+        TRY(check_launch("k_segment_fold_wide"));
+        profile_mark("k_segment_fold_wide", st);
+    }
+    k_segment_final_exp_wide<<<(unsigned)k, BLOCK, 0, st>>>(vals, d_seg_off, uniform_len, d_gt_out, k, n_vals, d_echo, fold);
+    TRY(check_launch("k_segment_final_exp_wide"));
+    profile_mark("k_segment_final_exp_wide", st);
+    return GPBC_OK;
+}
 static int multi_pair_dev_echo(const void *dP, const void *dQ, const uint64_t *d_seg_off, size_t n_pairs, size_t k,
                                void *d_gt_out, void *d_workspace, size_t workspace_bytes, uint64_t *d_echo, void *stream) {
     if (!k) return fail(GPBC_ERR_INVALID_ARG, "invalid inputs sizes");
@@ -610,18 +670,11 @@ static int multi_pair_dev_echo(const void *dP, const void *dQ, const uint64_t *d
     if (k <= g_wide_max.load() && n_pairs <= g_wide_max.load()) {              // the latency path: product and exponentiation per wavefront
         // segments of 32 values and more on average: fold them over 8 or 16 wavefronts first (a device-resident table is not
         // known here, so the average decides; a skewed table only makes the choice slower or faster, never wrong)
-        const unsigned fold = n_pairs >= 128 * k ? 16u : n_pairs >= 32 * k ? 8u : 0u;
-        if (fold) {
-            k_segment_fold_wide<<<(unsigned)(k * fold), BLOCK, 0, (hipStream_t)stream>>>((uint8_t *)d_workspace, d_seg_off, k, n_pairs, fold);
-            TRY(check_launch("k_segment_fold_wide"));
-            profile_mark("k_segment_fold_wide", (hipStream_t)stream);
-        }
-        k_segment_final_exp_wide<<<(unsigned)k, BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_workspace, d_seg_off, (uint8_t *)d_gt_out, k, n_pairs, d_echo, fold);
-        TRY(check_launch("k_segment_final_exp_wide"));
-        profile_mark("k_segment_final_exp_wide", (hipStream_t)stream);
-        return GPBC_OK;
+        return segments_wide((uint8_t *)d_workspace, d_seg_off, 0, k, n_pairs, (uint8_t *)d_gt_out, d_echo, (hipStream_t)stream);
     }
-    k_segment_product<<<grid_for(k), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_workspace, d_seg_off, (uint8_t *)d_gt_out, k, n_pairs, nullptr, d_echo);
+    uint64_t limit = 0;
+    TRY(segment_fold_passes((uint8_t *)d_workspace, d_seg_off, 0, k, n_pairs, (hipStream_t)stream, &limit));
+    k_segment_product<<<grid_for(k), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_workspace, d_seg_off, (uint8_t *)d_gt_out, k, n_pairs, nullptr, d_echo, limit);
     TRY(check_launch("k_segment_product"));
     profile_mark("k_segment_product", (hipStream_t)stream);
     return gpbc_final_exp_dev(d_gt_out, k, d_gt_out, stream);
@@ -881,7 +934,9 @@ static int multi_pair_core(const uint8_t *dP, const uint8_t *dQ, const uint64_t 
             TRY(check_launch("k_miller_accumulate_chunks"));
             profile_mark("k_miller_accumulate_chunks", st);
         }
-        k_segment_product<<<grid_for(k), BLOCK, 0, st>>>(dPart, dSegChunk, dG, k, n_chunks, dSeen, dEcho);
+        uint64_t limit = 0;
+        TRY(segment_fold_passes(dPart, dSegChunk, 0, k, n_chunks, st, &limit));
+        k_segment_product<<<grid_for(k), BLOCK, 0, st>>>(dPart, dSegChunk, dG, k, n_chunks, dSeen, dEcho, limit);
         TRY(check_launch("k_segment_product (segments)"));
         profile_mark("k_segment_product", st);
         TRY(gpbc_final_exp_dev(dG, k, dG, st));
@@ -907,6 +962,17 @@ int gpbc_multi_pair_fixed_q_dev(const void *dP, const void *dQ, size_t m, size_t
     if (!dP || !dQ || !d_gt_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
     TRY(bind_device());
     hipStream_t st = (hipStream_t)stream;
+    if (m * k <= g_wide_max.load() && g_multi_chunk.load() <= 0) {
+        // a few ciphertexts' worth of pairs (one BSW07 decrypt is 513): the line table of the list would be computed by m lanes at a
+        // lone lane's pace and cost more than it saves — every pair gets its own wavefront instead, the list indexed modulo m
+        Scratch tmp;
+        TRY(tmp.open(st, 0, Scratch::padded(m * k * GPBC_GT_BYTES)));
+        uint8_t *vals = tmp.take(m * k * GPBC_GT_BYTES);
+        k_miller_wide<<<(unsigned)(m * k), WIDE_MILLER_THREADS, 0, st>>>((const uint8_t *)dP, (const uint8_t *)dQ, vals, m * k, m);
+        TRY(check_launch("k_miller_wide"));
+        profile_mark("k_miller_wide", st);
+        return segments_wide(vals, nullptr, m, k, m * k, (uint8_t *)d_gt_out, nullptr, st);
+    }
     // Chunks of the Q list per lane pair: n_c equal chunks of L = ceil(m / n_c) <= FIXED_Q_CHUNK pairs.  One lane pair costs about
     // L line steps + 0.85 (its 64 squarings, in units of one pair's 88 line steps) and the chip runs 65536 lane pairs at a time, so
     // the estimate to minimise is  ceil(n_c k / 65536) * (L + 0.85): long chunks share squarings, but a last partly filled round of
@@ -944,7 +1010,9 @@ int gpbc_multi_pair_fixed_q_dev(const void *dP, const void *dQ, size_t m, size_t
         k_miller_accumulate_fixed_q<<<grid_for(2 * n_c * k), BLOCK, 0, st>>>(dPint, (const uint8_t *)dQ, dQ34, dPart, m, k, L, n_c);
         TRY(check_launch("k_miller_accumulate_fixed_q"));
         profile_mark("k_miller_accumulate_fixed_q", st);
-        k_chunk_product<<<grid_for(k), BLOCK, 0, st>>>(dPart, (uint8_t *)d_gt_out, k, n_c);      // ciphertext j owns chunk values [j n_c, (j+1) n_c)
+        uint64_t limit = 0;
+        TRY(segment_fold_passes(dPart, nullptr, n_c, k, n_c * k, st, &limit));
+        k_chunk_product<<<grid_for(k), BLOCK, 0, st>>>(dPart, (uint8_t *)d_gt_out, k, n_c, limit);      // ciphertext j owns chunk values [j n_c, (j+1) n_c)
         TRY(check_launch("k_chunk_product"));
         profile_mark("k_chunk_product", st);
     }

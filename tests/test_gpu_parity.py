@@ -244,6 +244,13 @@ def test_latency_path_matches_the_throughput_kernels(eng, oracle):
             got_r, got_1 = eng.multi_pair(P[:600], Q[:600], ragged), eng.multi_pair(P[:513], Q[:513], np.array([0, 513], dtype=np.uint64))
             if knob == 0:
                 want_r, want_1 = got_r, got_1
+                # the throughput kernels fold long segments too (k_segment_fold: passes of 512 / 64 / 8 lane pairs per segment before
+                # the one-thread product) — also over the CHUNK values of the shared-squaring form: 2-pair chunks, 281 of them in one segment
+                _lib.check(lib.gpbc_set_multi_pair_chunk(2))
+                try:
+                    assert (eng.multi_pair(P[:600], Q[:600], ragged) == want_r).all()
+                finally:
+                    lib.gpbc_set_multi_pair_chunk(0)
             assert (got_r == want_r).all() and (got_1 == want_1).all(), knob
     finally:
         lib.gpbc_set_latency_path(2048)

@@ -131,14 +131,17 @@ void profile_mark(const char *kernel_name, hipStream_t st);   // bench.py's per-
 int sync_default();
 
 // RAII device buffer for the host-pointer entry points
+// Device blocks of the host-pointer entries.  hipMalloc / hipFree per call cost 0.1-0.2 ms on a good day and, now and then, 10 ms and
+// more (profiles/r03_size_sweep.txt: a 1.6 ms decode call measured at 12-15 ms) — so freed blocks go to a small per-device cache
+// (gpbc_core.hip: size classes, at most 1 GiB kept per device, gpbc_release_workspaces() empties it) and come back from there.
+// A block returns to the cache only after the device has drained, which is what hipFree's implicit synchronisation did.
+int dev_block_alloc(size_t bytes, void **p, size_t *cap);
+void dev_block_free(void *p, size_t cap);
 struct DevBuf {
     void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(size_t bytes) {
-        hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
-        if (e != hipSuccess) { p = nullptr; return fail(GPBC_ERR_HIP, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
-        return GPBC_OK;
-    }
+    size_t cap = 0;
+    ~DevBuf() { if (p) dev_block_free(p, cap); }
+    int alloc(size_t bytes) { return dev_block_alloc(bytes ? bytes : 1, &p, &cap); }
     int upload(const void *src, size_t bytes) {
         TRY(alloc(bytes));
         if (bytes) HIP_TRY(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));

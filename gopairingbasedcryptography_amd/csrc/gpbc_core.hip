@@ -151,7 +151,66 @@ static int stream_buffer(int kind, hipStream_t stream, size_t bytes, void **out)
 int stream_workspace(hipStream_t stream, size_t bytes, int32_t **out) { return stream_buffer(0, stream, bytes, (void **)out); }
 int stream_scratch(hipStream_t stream, int level, size_t bytes, void **out) { return stream_buffer(1 + level, stream, bytes, out); }
 int pinned_staging(hipStream_t stream, size_t bytes, uint8_t **out) { return stream_buffer(KIND_PINNED, stream, bytes < 4096 ? 4096 : bytes, (void **)out); }
+// ---- cache of the host-pointer entries' device blocks (DevBuf).  Classes: powers of two from 4 KiB to 64 MiB, multiples of 64 MiB
+// above; a cached block serves a request of its class only, so at most twice the asked-for bytes are held per block.
+struct DevBlock { int device; void *ptr; size_t cap; };
+static std::mutex g_blk_mu;
+static std::vector<DevBlock> g_blk;
+static size_t g_blk_bytes[MAX_DEVICES] = {};
+constexpr size_t BLK_KEEP_PER_DEVICE = (size_t)1 << 30, BLK_BIG = (size_t)64 << 20;
+void free_device_blocks();
+static size_t blk_class(size_t bytes) {
+    if (bytes > BLK_BIG) return (bytes + BLK_BIG - 1) / BLK_BIG * BLK_BIG;
+    size_t c = 4096;
+    while (c < bytes) c <<= 1;
+    return c;
+}
+int dev_block_alloc(size_t bytes, void **p, size_t *cap) {
+    const size_t c = blk_class(bytes);
+    const int dev = cur_index();
+    {
+        std::lock_guard<std::mutex> lk(g_blk_mu);
+        for (size_t i = 0; i < g_blk.size(); i++)
+            if (g_blk[i].device == dev && g_blk[i].cap == c) {
+                *p = g_blk[i].ptr; *cap = c;
+                g_blk_bytes[dev] -= c;
+                g_blk[i] = g_blk.back(); g_blk.pop_back();
+                return GPBC_OK;
+            }
+    }
+    hipError_t e = hipMalloc(p, c);
+    if (e != hipSuccess) {                                   // memory held by the cache may be what is missing: empty it and try once more
+        free_device_blocks();
+        e = hipMalloc(p, c);
+    }
+    if (e != hipSuccess) { *p = nullptr; *cap = 0; return fail(GPBC_ERR_HIP, "hipMalloc(%zu) failed: %s", c, hipGetErrorString(e)); }
+    *cap = c;
+    return GPBC_OK;
+}
+void dev_block_free(void *p, size_t cap) {
+    const int dev = cur_index();
+    (void)hipDeviceSynchronize();                             // nothing in flight may still use the block (what hipFree guarantees)
+    {
+        std::lock_guard<std::mutex> lk(g_blk_mu);
+        if (dev >= 0 && dev < MAX_DEVICES && g_blk_bytes[dev] + cap <= BLK_KEEP_PER_DEVICE) {
+            g_blk.push_back(DevBlock{dev, p, cap});
+            g_blk_bytes[dev] += cap;
+            return;
+        }
+    }
+    (void)hipFree(p);
+}
+void free_device_blocks() {
+    std::lock_guard<std::mutex> lk(g_blk_mu);
+    int keep = -1;
+    (void)hipGetDevice(&keep);
+    for (auto &b : g_blk) { if (g_ctx[b.device].hip >= 0) (void)hipSetDevice(g_ctx[b.device].hip); (void)hipFree(b.ptr); }
+    g_blk.clear();
+    for (auto &x : g_blk_bytes) x = 0;
+    if (keep >= 0) (void)hipSetDevice(keep);
+}
 void free_workspaces() {
+    free_device_blocks();
     std::lock_guard<std::mutex> lk(g_ws_mu);
     for (auto &w : g_ws) if (w.ptr) { if (g_ctx[w.device].hip >= 0) (void)hipSetDevice(g_ctx[w.device].hip); (void)ws_free(w.kind, w.ptr); }
     g_ws.clear();

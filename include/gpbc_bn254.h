@@ -129,7 +129,9 @@ int gpbc_multi_pair_hostseg_dev(const void *dP, const void *dQ, const uint64_t *
  * same for every ciphertext), one public key against k signatures.  The line coefficients of each Q_i are computed once
  * and reused by all k segments (gnark: PrecomputeLines / MillerLoopFixedQ), on top of the shared squarings; results are
  * bit-identical to gpbc_multi_pair on the replicated list.  P: k*m points, segment-major.  The _dev form is asynchronous on
- * `stream`; its temporaries (line table, converted points, chunk values) stay in a per-stream scratch buffer between calls. */
+ * `stream`; its temporaries (line table, converted points, chunk values) stay in a per-stream scratch buffer between calls.
+ * Calls of at most gpbc_set_latency_path's limit in total (k*m pairs; one ciphertext is 513) skip the line table — m lone lanes
+ * would spend longer building it than it saves — and run one pairing per wavefront with the list indexed modulo m: 1.5 ms. */
 int gpbc_multi_pair_fixed_q(const void *P, const void *Q, size_t m, size_t k, void *gt_out);
 int gpbc_multi_pair_fixed_q_dev(const void *dP, const void *dQ, size_t m, size_t k, void *d_gt_out, void *stream);
 /* Tuning / test knob of the multi-pairing paths: pairs per shared-squaring chunk, 1..64 (the general path, whose lines live in a

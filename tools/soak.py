@@ -82,6 +82,12 @@ for trial in range(16):
     o2 = np.concatenate([[0], cuts, [int(rng.integers(max(int(cuts[-1]) if ks > 1 else 1, 1), 2049))]]).astype(np.uint64)
     ii = rng.integers(0, n, size=int(o2[-1]))
     assert (bn254.multi_pair(P[ii], Q[ii], o2) == oracle_lib.multi_pair(P[ii], Q[ii], o2, threads=threads)).all(), ("folded multi-pairing", trial, o2)
+# ... a few LONG segments through the throughput kernels (k_segment_fold before the one-thread products): 5 000-pair calls over Miller
+# values, and — with more than 131 072 pairs, where segments are cut into shared-squaring chunks — over chunk values
+for sizes in ([1500, 3000, 1, 700], [5000], [70000, 0, 90000] if n >= 160000 else [30000, 0, 20000]):
+    o2 = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    ii = rng.integers(0, n, size=int(o2[-1]))
+    assert (bn254.multi_pair(P[ii], Q[ii], o2) == oracle_lib.multi_pair(P[ii], Q[ii], o2, threads=threads)).all(), ("long segments", sizes)
 print("multi-pairings ok  (%d segments, %d pairs, %.1f s)" % (len(lens), m, time.time() - t0), flush=True)
 t0 = time.time()
 ke = scal(4096, full=True)

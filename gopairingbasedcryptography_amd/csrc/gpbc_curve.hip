@@ -1,6 +1,7 @@
 // libgpbc_bn254.so, unit 3 of 4: G1 / G2 scalar multiplication, point sums, fixed-base window tables and the sums over
 // them, with their C-ABI entries (include/gpbc_bn254.h).  gfx950 only.
 #include "gpbc_common.hpp"
+#include "curve29_quad.hip.hpp"
 
 // Scalar multiplication: a lane owns SMUL_K points (t, t+T, t+2T, ...; T = ceil(n / SMUL_K)) whose Jacobian results share
 // one field inversion.  Measured on MI355X (2^20 points): K = 1 -> 36.9 M G1 / 15.0 M G2 per second, K = 2 -> 36.9 / 13.7,
@@ -45,6 +46,37 @@ GPBC_KERNEL k_g2_scalar_mul(const uint8_t *__restrict__ bases, int shared_base, 
         size_t i = t + (size_t)j * T;
         if (i < n) g2_store_aff(out + i * GPBC_G2_BYTES, aff[j]);
     }
+}
+
+// The same for calls too small to fill the chip with one point per lane (up to SMUL_QUAD_MAX points): one point per QUAD, the loop's
+// doublings and additions three products wide (csrc/curve29_quad.hip.hpp) — a lone lane walks the ~1 600 (G1) / ~2 300 (G2) dependent
+// products of a scalar multiplication at a fixed pace whatever the batch, so the depth of the formulas is what such a call pays for.
+constexpr size_t SMUL_QUAD_MAX = 16384;     // measured: 16 384 points 0.95 / 1.43 ms (G1 / G2) against 1.27 / 2.09 with one point per lane; 20 000: 1.26 / 2.24 — slower
+GPBC_KERNEL_G1 k_g1_scalar_mul_quad(const uint8_t *__restrict__ bases, int shared_base, const uint8_t *__restrict__ scalars, uint8_t *__restrict__ out, size_t n, int32_t *__restrict__ tabws) {
+    const size_t lane = (size_t)blockIdx.x * BLOCK + threadIdx.x, i = lane >> 2;
+    const int q = (int)(lane & 3);
+    if (i >= n) return;
+    AffP<Fe> b = g1_load_aff(bases + (shared_base ? 0 : i * GPBC_G1_BYTES));
+    uint32_t k[8];
+    load_scalar(k, scalars + i * GPBC_SCALAR_BYTES);
+    JacP<Fe> res;
+    scalar_mul29_jac_quad<Fe>(res, b, k, tabws + i * (size_t)glv_table_dwords<Fe>(), q);
+    AffP<Fe> aff;
+    jac_to_affine(aff, res);
+    if (q == 0) g1_store_aff(out + i * GPBC_G1_BYTES, aff);
+}
+GPBC_KERNEL k_g2_scalar_mul_quad(const uint8_t *__restrict__ bases, int shared_base, const uint8_t *__restrict__ scalars, uint8_t *__restrict__ out, size_t n, int32_t *__restrict__ tabws) {
+    const size_t lane = (size_t)blockIdx.x * BLOCK + threadIdx.x, i = lane >> 2;
+    const int q = (int)(lane & 3);
+    if (i >= n) return;
+    AffP<F2> b = g2_load_aff(bases + (shared_base ? 0 : i * GPBC_G2_BYTES));
+    uint32_t k[8];
+    load_scalar(k, scalars + i * GPBC_SCALAR_BYTES);
+    JacP<F2> res;
+    scalar_mul29_gls_quad(res, b, k, tabws + i * (size_t)glv_table_dwords<F2>(), q);
+    AffP<F2> aff;
+    jac_to_affine(aff, res);
+    if (q == 0) g2_store_aff(out + i * GPBC_G2_BYTES, aff);
 }
 
 // one level of the point-sum tree: thread t adds in[t], in[t+n_out], in[t+2 n_out], ... -> out[t] (affine)
@@ -189,6 +221,13 @@ static int scalar_mul_dev(bool g2, const void *d_bases, size_t nbase, const void
         const size_t m = n - off < chunk ? n - off : chunk;
         const uint8_t *b = (const uint8_t *)d_bases + (shared ? 0 : off * pt), *k = (const uint8_t *)d_scalars + off * GPBC_SCALAR_BYTES;
         uint8_t *o = (uint8_t *)d_out + off * pt;
+        if (n <= SMUL_QUAD_MAX) {
+            if (g2) k_g2_scalar_mul_quad<<<grid_for(4 * m), BLOCK, 0, st>>>(b, shared, k, o, m, tabws);
+            else k_g1_scalar_mul_quad<<<grid_for(4 * m), BLOCK, 0, st>>>(b, shared, k, o, m, tabws);
+            TRY(check_launch(g2 ? "k_g2_scalar_mul_quad" : "k_g1_scalar_mul_quad"));
+            profile_mark(g2 ? "k_g2_scalar_mul_quad" : "k_g1_scalar_mul_quad", st);
+            continue;
+        }
         if (g2) k_g2_scalar_mul<<<grid_for(m), BLOCK, 0, st>>>(b, shared, k, o, m, tabws);
         else k_g1_scalar_mul<<<grid_for(m), BLOCK, 0, st>>>(b, shared, k, o, m, tabws);
         TRY(check_launch(g2 ? "k_g2_scalar_mul" : "k_g1_scalar_mul"));

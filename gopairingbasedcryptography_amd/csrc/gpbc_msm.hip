@@ -16,6 +16,7 @@
 // All scratch is one stream-ordered allocation; the call is asynchronous on `stream`.
 #include "gpbc_common.hpp"
 #include "msm29.hip.hpp"
+#include "curve29_quad.hip.hpp"
 
 constexpr int SCAN_BLOCK = 256, SCAN_ITEMS = 4, SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
 
@@ -189,28 +190,7 @@ k_msm_rows_sum(const int32_t *__restrict__ in, size_t n_out, size_t fan, int32_t
 // Horner over the windows is ONE chain of (W - 1) c doublings — 240 for sixteen 16-bit windows — and a lone lane walks it at ~14 k
 // cycles per doubling: a quarter of a 2^20-term sum was this kernel.  The seven products of jac_dbl are three levels deep
 // (X^2, Y^2, Y 2Z | X 4B, B 8B, (3A)^2 | E (S - x3)), so three lanes of a quad take one product each per level and pass the results
-// round by DPP broadcasts: three product times per doubling instead of seven.  Every lane of the quad holds the whole point and runs
-// the linear parts itself; the values are those of jac_dbl (squares taken as general products).
-template <int SRC> __device__ __forceinline__ Fe quad_bcast(const Fe &a) {
-    Fe r;
-#pragma unroll
-    for (int i = 0; i < NL; i++) r.v[i] = __builtin_amdgcn_mov_dpp(a.v[i], SRC * 0x55, 0xF, 0xF, true);   // quad_perm [SRC, SRC, SRC, SRC]
-    return r;
-}
-template <int SRC> __device__ __forceinline__ F2 quad_bcast(const F2 &a) { return F2{quad_bcast<SRC>(a.a0), quad_bcast<SRC>(a.a1)}; }
-template <class F> __device__ __forceinline__ void jac_dbl_quad(JacP<F> &p, int q) {
-    if (p.inf) return;                                          // the same on every lane
-    const F z2 = g_norm(g_dbl(p.z));
-    const F p1 = g_mul(g_sel<F>(q == 0, p.x, p.y), g_sel<F>(q == 0, p.x, g_sel<F>(q == 1, p.y, z2)));   // lane 0: A = X^2, 1: B = Y^2, 2: z3 = Y 2Z
-    const F A = quad_bcast<0>(p1), B = quad_bcast<1>(p1), z3 = quad_bcast<2>(p1);
-    const F B4 = g_norm(g_dbl(g_dbl(B)));
-    const F E = g_norm(g_add(g_dbl(A), A));
-    const F p2 = g_mul(g_sel<F>(q == 0, E, g_sel<F>(q == 1, B, p.x)), g_sel<F>(q == 0, E, g_sel<F>(q == 1, g_norm(g_dbl(B4)), B4)));   // 0: FF = E^2, 1: C8 = B 8B, 2: S = X 4B
-    const F FF = quad_bcast<0>(p2), C8 = quad_bcast<1>(p2), S = quad_bcast<2>(p2);
-    const F x3 = g_norm(g_sub(FF, g_dbl(S)));
-    p.y = g_sub(g_mul(E, g_sub(S, x3)), C8);
-    p.x = x3; p.z = z3;
-}
+// round by DPP broadcasts (jac_dbl_quad, csrc/curve29_quad.hip.hpp): three product times per doubling instead of seven.
 template <class F> __global__ void __launch_bounds__(BLOCK) k_msm_finish(const int32_t *__restrict__ window_sums, int c, int W, uint8_t *__restrict__ out) {
     if (blockIdx.x != 0 || threadIdx.x >= 4) return;            // one quad
     const int q = threadIdx.x;

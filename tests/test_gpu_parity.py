@@ -366,6 +366,28 @@ def test_point_sums(eng, oracle, synth):
     assert not eng.g1_sum(np.zeros(0, dtype=np.uint8)).any()
 
 
+def test_scalar_mul_one_point_per_quad_and_per_lane_agree(eng, oracle):
+    """Calls of up to 16 384 points run one point per QUAD of lanes (csrc/curve29_quad.hip.hpp: the loop's doublings and additions three
+    products wide), larger ones one point per lane: the same random points and 256-bit scalars through both, and against the oracle on a
+    sample; infinity, zero and tiny scalars, and a shared base included."""
+    g1, g2 = eng.generators()
+    n = 16385
+    rng = np.random.default_rng(77)
+    k1 = rng.integers(0, 256, size=(n, 32), dtype=np.uint8); k1[:, 31] &= 0x1f
+    k2 = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    k2[:4] = 0; k2[1, 0], k2[2, 0], k2[3, 0] = 1, 2, 3
+    pick = np.r_[0:8, 100:108, n - 9:n - 1]
+    for gen, mul, omul, w in ((g1, eng.g1_scalar_mul, oracle.g1_scalar_mul, 64), (g2, eng.g2_scalar_mul, oracle.g2_scalar_mul, 128)):
+        base = mul(gen, k1.reshape(-1)).reshape(n, w).copy()       # n > 16 384 with one shared base: the fixed-base path
+        base[5] = 0
+        lane = mul(base, k2.reshape(-1)).reshape(n, w)              # one point per lane
+        quad = mul(base[:16384], k2[:16384].reshape(-1)).reshape(16384, w)
+        assert (quad == lane[:16384]).all()
+        assert (lane[pick] == np.asarray(omul(base[pick], k2[pick].reshape(-1), threads=8)).reshape(-1, w)).all()
+        shared = mul(base[7], k2[:300].reshape(-1)).reshape(300, w)  # one base, 300 scalars: the quad kernel's shared-base form
+        assert (shared == np.asarray(omul(np.tile(base[7], (300, 1)), k2[:300].reshape(-1), threads=8)).reshape(-1, w)).all()
+
+
 def test_scalar_mul_base_through_generator_tables(eng, oracle):
     """ScalarMultiplicationBase for small host calls runs on fixed-base tables of the generators (as the C++ and Go host sides do):
     same bytes as the variable-base kernel on the generator and as the oracle, zero and r - 1 and a 256-bit pattern included."""

@@ -940,6 +940,13 @@ def test_hash_to_curve_large_batch_properties(eng):
         assert ok.all() and (back == pts).all()
         assert len({r.tobytes() for r in pts}) == n and pts.any(axis=1).all()        # distinct, none at infinity
     assert (hash_to.hash_to_g2(msgs[:64], hash_to.DST_BYTES_G2) == H2[:64]).all()
+    # calls of up to 16 384 messages run one message per QUAD of lanes (the two maps side by side, G2's cofactor clearing three products
+    # wide), larger ones one message per lane: the same messages through both, and a sample against the big-integer restatement
+    big = msgs + [b"and %d more" % i for i in range(16385 - n)]
+    L1, L2 = hash_to.hash_to_g1(big, hash_to.DST_BYTES_G1), hash_to.hash_to_g2(big, hash_to.DST_BYTES_G2)
+    assert (L1[:n] == H1).all() and (L2[:n] == H2).all()
+    for i in (0, 1, n - 1, 16384):
+        assert L1[i].tobytes() == o.g1_to_bytes(o.hash_to_g1(big[i], hash_to.DST_BYTES_G1)) and L2[i].tobytes() == o.g2_to_bytes(o.hash_to_g2(big[i], hash_to.DST_BYTES_G2))
     m = 256
     g1, g2 = eng.generators()
     sk = scalars("bls-sk", m)

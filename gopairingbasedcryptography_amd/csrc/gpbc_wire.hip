@@ -32,6 +32,36 @@ GPBC_KERNEL k_g2_decode(const uint8_t *__restrict__ in, int elem_bytes, uint8_t 
     if (i >= n) return;
     ok[i] = g2_wire_decode(out + i * GPBC_G2_BYTES, in + i * (size_t)elem_bytes, elem_bytes) ? 1 : 0;
 }
+// G2 decoding with one element per QUAD of lanes (calls of up to WIRE_QUAD_MAX elements): the 63-bit double-and-add of the subgroup
+// test — two thirds of a decode — three products wide (csrc/curve29_quad.hip.hpp); the four lanes decode the same element and take
+// the same branches.
+constexpr size_t WIRE_QUAD_MAX = 16384;
+__device__ __forceinline__ bool g2_in_subgroup29_quad(const F2 &x, const F2 &y, int q) {
+    constexpr uint64_t X = 4965661367192848881ull;
+    AffP<F2> pt{x, y, false};
+    JacP<F2> xq;
+    jac_set_inf(xq);
+    for (int i = 62; i >= 0; i--) {
+        jac_dbl_quad(xq, q);
+        if ((X >> i) & 1) jac_add_mixed_quad(xq, pt, q);
+    }
+    JacP<F2> lhs, t, rhs;
+    jac_add_mixed(lhs, xq, pt);                                  // [x+1]Q
+    jac_add(lhs, lhs, jac_psi_tw(xq, 1));
+    jac_add(lhs, lhs, jac_psi_tw(xq, 2));
+    jac_dbl(t, xq);
+    rhs = jac_psi_tw(t, 3);
+    if (!rhs.inf) rhs.y = f2_neg(rhs.y);
+    jac_add(t, lhs, rhs);                                        // lhs - rhs
+    return t.inf;
+}
+GPBC_KERNEL k_g2_decode_quad(const uint8_t *__restrict__ in, int elem_bytes, uint8_t *__restrict__ out, uint8_t *__restrict__ ok, size_t n) {
+    const size_t lane = (size_t)blockIdx.x * BLOCK + threadIdx.x, i = lane >> 2;
+    if (i >= n) return;
+    const int q = (int)(lane & 3);
+    const bool good = g2_wire_decode(out + i * GPBC_G2_BYTES, in + i * (size_t)elem_bytes, elem_bytes, [&](const F2 &x, const F2 &y) { return g2_in_subgroup29_quad(x, y, q); });
+    if (q == 0) ok[i] = good ? 1 : 0;                            // (the four lanes wrote the same point bytes)
+}
 GPBC_KERNEL k_gt_decode(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, uint8_t *__restrict__ ok, size_t n) {
     size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -208,6 +238,7 @@ static int unmarshal_dev(int kind, const void *d_in, size_t elem_bytes, size_t n
     TRY(bind_device());
     hipStream_t st = (hipStream_t)stream;
     if (kind == 0) k_g1_decode<<<grid_for(n), BLOCK, 0, st>>>((const uint8_t *)d_in, (int)elem_bytes, (uint8_t *)d_out, d_ok, n);
+    else if (kind == 1 && n <= WIRE_QUAD_MAX) k_g2_decode_quad<<<grid_for(4 * n), BLOCK, 0, st>>>((const uint8_t *)d_in, (int)elem_bytes, (uint8_t *)d_out, d_ok, n);
     else if (kind == 1) k_g2_decode<<<grid_for(n), BLOCK, 0, st>>>((const uint8_t *)d_in, (int)elem_bytes, (uint8_t *)d_out, d_ok, n);
     else k_gt_decode<<<grid_for(n), BLOCK, 0, st>>>((const uint8_t *)d_in, (uint8_t *)d_out, d_ok, n);
     return check_launch("wire decode");

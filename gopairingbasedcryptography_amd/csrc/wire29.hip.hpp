@@ -262,7 +262,8 @@ GPBC_NOINLINE bool g2_in_subgroup29(const F2 &x, const F2 &y) {
     jac_add(t, lhs, rhs);                                        // lhs - rhs
     return t.inf;
 }
-GPBC_INLINE bool g2_wire_decode(uint8_t *out, const uint8_t *in, int elem_bytes) {
+// `in_subgroup(x, y)`: the membership test to use (g2_in_subgroup29, or its one-point-per-quad form in small calls: gpbc_wire.hip)
+template <class Sub> GPBC_INLINE bool g2_wire_decode(uint8_t *out, const uint8_t *in, int elem_bytes, Sub &&in_subgroup) {
     wire_zero_bytes(out, 128);
     const uint8_t flag = in[0] & WIRE_MASK;
     constexpr int32_t BT[2][NL] = F29_B_G2;
@@ -287,10 +288,13 @@ GPBC_INLINE bool g2_wire_decode(uint8_t *out, const uint8_t *in, int elem_bytes)
         if (!ok) return false;
         if (f2_lex_largest(y) != (flag == WIRE_LARGEST)) y = f2_neg(y);
     }
-    if (!g2_in_subgroup29(x, y)) return false;                          // "subgroup check failed"
+    if (!in_subgroup(x, y)) return false;                               // "subgroup check failed"
     f2_store(out, x);
     f2_store(out + 64, y);
     return true;
+}
+GPBC_INLINE bool g2_wire_decode(uint8_t *out, const uint8_t *in, int elem_bytes) {
+    return g2_wire_decode(out, in, elem_bytes, [](const F2 &x, const F2 &y) { return g2_in_subgroup29(x, y); });
 }
 
 // ---- GT: coefficient k of the memory order C0.B0.A0 ... C1.B2.A1 sits at wire position 11 - k

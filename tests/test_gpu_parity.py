@@ -384,6 +384,15 @@ def test_scalar_mul_one_point_per_quad_and_per_lane_agree(eng, oracle):
         quad = mul(base[:16384], k2[:16384].reshape(-1)).reshape(16384, w)
         assert (quad == lane[:16384]).all()
         assert (lane[pick] == np.asarray(omul(base[pick], k2[pick].reshape(-1), threads=8)).reshape(-1, w)).all()
+        if w == 128:                                                # G2 decoding: the subgroup test per quad (<= 16 384) and per lane
+            enc = np.asarray(eng.g2_marshal(lane, compressed=True)).reshape(n, 64)
+            back_l, ok_l = eng.g2_unmarshal(enc.reshape(-1), elem_bytes=64)
+            back_q, ok_q = eng.g2_unmarshal(enc[:16384].reshape(-1), elem_bytes=64)
+            assert ok_l.all() and ok_q.all() and (back_l == lane).all() and (back_q == lane[:16384]).all()
+            bad = enc.copy(); bad[9, 40] ^= 1; bad[16384, 40] ^= 1    # a flipped bit of x: no square root, or a point outside the subgroup
+            _, okb_l = eng.g2_unmarshal(bad.reshape(-1), elem_bytes=64)
+            _, okb_q = eng.g2_unmarshal(bad[:16384].reshape(-1), elem_bytes=64)
+            assert not okb_l[9] and not okb_l[16384] and not okb_q[9] and okb_l.sum() == n - 2 and okb_q.sum() == 16383
         shared = mul(base[7], k2[:300].reshape(-1)).reshape(300, w)  # one base, 300 scalars: the quad kernel's shared-base form
         assert (shared == np.asarray(omul(np.tile(base[7], (300, 1)), k2[:300].reshape(-1), threads=8)).reshape(-1, w)).all()
 

@@ -706,7 +706,9 @@ int gpbc_gt_exp_batch_dev(const void *d_x, const void *d_k, size_t n, void *d_ou
     if (!d_x || !d_k || !d_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
     TRY(bind_device());
     hipStream_t st = (hipStream_t)stream;
-    if (n <= g_wide_max.load()) {
+    // one round of the chip holds 2 048 wavefronts (1.1 ms per round when full), the lane-pair kernel needs 3.6 ms whatever the size
+    // below 65 536: measured 2 048 / 4 096 / 8 192 elements 1.09 / 2.45 / 4.23 ms against 3.6 — two rounds is where the wavefront form stops winning
+    if (n <= 2 * g_wide_max.load()) {
         k_gt_exp_wide<<<(unsigned)n, BLOCK, 0, st>>>((const uint8_t *)d_x, (const uint8_t *)d_k, (uint8_t *)d_out, n);
         TRY(check_launch("k_gt_exp_wide"));
         profile_mark("k_gt_exp_wide", st);

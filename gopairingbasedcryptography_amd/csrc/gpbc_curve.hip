@@ -131,9 +131,14 @@ GPBC_KERNEL k_g2_fb_build(const uint8_t *__restrict__ bases, size_t nbase, int32
 // multi-scalar multiplication over the tables: lane (c, m) adds the terms of MSM m for bases [c*C, (c+1)*C): 32 mixed
 // additions per term, no doublings.  Partials are written chunk-major (partial[c * n_msm + m]) so that ONE launch of the
 // strided point-sum kernel adds the chunks of every MSM.
-template <class F> __device__ __forceinline__ void fb_msm_lane(const int32_t *table, const uint8_t *base_inf, size_t nbase, const uint8_t *scalars,
+// QUAD: one (chunk, sum) per quad of lanes, the additions five products deep instead of eleven long (csrc/curve29_quad.hip.hpp) — for
+// calls with so few (chunk, sum) pairs that a lone lane's chain of additions is all the call consists of (one ScalarMultiplicationBase:
+// 32 additions; one 256-term commitment)
+template <class F, bool QUAD = false> __device__ __forceinline__ void fb_msm_lane(const int32_t *table, const uint8_t *base_inf, size_t nbase, const uint8_t *scalars,
                                                                size_t n_msm, size_t C, size_t n_chunks, uint8_t *partial) {
-    size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    const size_t lane = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    size_t t = QUAD ? lane >> 2 : lane;
+    const int q = (int)(lane & 3);
     if (t >= n_msm * n_chunks) return;
     const size_t m = t % n_msm, c = t / n_msm;
     JacP<F> acc;
@@ -149,12 +154,13 @@ template <class F> __device__ __forceinline__ void fb_msm_lane(const int32_t *ta
             if (d) {
                 AffP<F> e;
                 tab_load(tb + (size_t)(w * FB_DIGITS + d - 1) * TabLayout<F>::ENTRY_DWORDS, 0, e);
-                jac_add_mixed(acc, acc, e);
+                if constexpr (QUAD) jac_add_mixed_quad(acc, e, q); else jac_add_mixed(acc, acc, e);
             }
         }
     }
     AffP<F> a;
     jac_to_affine(a, acc);
+    if (QUAD && q != 0) return;
     if constexpr (sizeof(F) == sizeof(Fe)) g1_store_aff(partial + t * GPBC_G1_BYTES, a); else g2_store_aff(partial + t * GPBC_G2_BYTES, a);
 }
 GPBC_KERNEL_G1 k_g1_fb_msm(const int32_t *__restrict__ table, const uint8_t *__restrict__ base_inf, size_t nbase, const uint8_t *__restrict__ scalars,
@@ -164,6 +170,16 @@ GPBC_KERNEL_G1 k_g1_fb_msm(const int32_t *__restrict__ table, const uint8_t *__r
 GPBC_KERNEL k_g2_fb_msm(const int32_t *__restrict__ table, const uint8_t *__restrict__ base_inf, size_t nbase, const uint8_t *__restrict__ scalars,
                         size_t n_msm, size_t C, size_t n_chunks, uint8_t *__restrict__ partial) {
     fb_msm_lane<F2>(table, base_inf, nbase, scalars, n_msm, C, n_chunks, partial);
+}
+
+constexpr size_t FB_QUAD_MAX = 16384;              // (chunk, sum) pairs per call up to which the quad form is taken
+GPBC_KERNEL_G1 k_g1_fb_msm_quad(const int32_t *__restrict__ table, const uint8_t *__restrict__ base_inf, size_t nbase, const uint8_t *__restrict__ scalars,
+                                size_t n_msm, size_t C, size_t n_chunks, uint8_t *__restrict__ partial) {
+    fb_msm_lane<Fe, true>(table, base_inf, nbase, scalars, n_msm, C, n_chunks, partial);
+}
+GPBC_KERNEL k_g2_fb_msm_quad(const int32_t *__restrict__ table, const uint8_t *__restrict__ base_inf, size_t nbase, const uint8_t *__restrict__ scalars,
+                             size_t n_msm, size_t C, size_t n_chunks, uint8_t *__restrict__ partial) {
+    fb_msm_lane<F2, true>(table, base_inf, nbase, scalars, n_msm, C, n_chunks, partial);
 }
 
 extern "C" {
@@ -514,7 +530,10 @@ int gpbc_fixed_base_msm_dev(const gpbc_fixed_base *h, const void *d_scalars, siz
     const size_t pt = h->is_g2 ? GPBC_G2_BYTES : GPBC_G1_BYTES;
     uint8_t *partial = n_chunks > 1 ? (uint8_t *)d_workspace : (uint8_t *)d_out;
     const size_t lanes = n_msm * n_chunks;
-    if (h->is_g2) k_g2_fb_msm<<<grid_for(lanes), BLOCK, 0, st>>>(h->table, h->base_inf, h->nbase, (const uint8_t *)d_scalars, n_msm, C, n_chunks, partial);
+    if (lanes <= FB_QUAD_MAX) {
+        if (h->is_g2) k_g2_fb_msm_quad<<<grid_for(4 * lanes), BLOCK, 0, st>>>(h->table, h->base_inf, h->nbase, (const uint8_t *)d_scalars, n_msm, C, n_chunks, partial);
+        else k_g1_fb_msm_quad<<<grid_for(4 * lanes), BLOCK, 0, st>>>(h->table, h->base_inf, h->nbase, (const uint8_t *)d_scalars, n_msm, C, n_chunks, partial);
+    } else if (h->is_g2) k_g2_fb_msm<<<grid_for(lanes), BLOCK, 0, st>>>(h->table, h->base_inf, h->nbase, (const uint8_t *)d_scalars, n_msm, C, n_chunks, partial);
     else k_g1_fb_msm<<<grid_for(lanes), BLOCK, 0, st>>>(h->table, h->base_inf, h->nbase, (const uint8_t *)d_scalars, n_msm, C, n_chunks, partial);
     TRY(check_launch("k_fb_msm"));
     profile_mark(h->is_g2 ? "k_g2_fb_msm" : "k_g1_fb_msm", st);

@@ -351,6 +351,27 @@ __global__ void __launch_bounds__(WIDE_MILLER_THREADS, 2) k_miller_wide(const ui
         m.run(6, [&](int k) { f2_store(f_out + i * GPBC_GT_BYTES + 64 * k, m.ld(k)); });
     }
 }
+// The fixed-Q form's line table (k_q_lines) by the latency form's G2 walk, one Q_i per wavefront (lists of up to the latency limit: a key's 513 points on 513 lone
+// lanes took longer than everything else in a call of a few ciphertexts).  wide_miller_lines evaluates its lines at P; at P = (1, 1)
+// they are the raw coefficients — up to the factor in Fp2 that k_q_lines_scale divides out anyway.
+GPBC_KERNEL k_q_lines_wide(const uint8_t *__restrict__ Q, int32_t *__restrict__ qlines, size_t m_pts) {
+    __shared__ w128 w_mem[W_SLOTS * 6];
+    const size_t i = blockIdx.x;
+    if (i >= m_pts) return;
+    const uint8_t *q = Q + i * GPBC_G2_BYTES;
+    if (g2_bytes_inf(q)) return;
+    const WideLds m{w_mem, (int)threadIdx.x};
+    const G1A a{fe_one(), fe_one()};
+    const G2A b{f2_load(q), f2_load(q + 64)};
+    wide_miller_lines(m, a, b, [&](int j) {
+        m.run(3, [&](int t) {
+            const F2 c = m.ld(W_L0 + t);
+            int32_t *o = qlines + (size_t)j * LINE_WORDS * m_pts + i;
+#pragma unroll
+            for (int w = 0; w < NL; w++) { o[(size_t)((2 * t) * NL + w) * m_pts] = c.a0.v[w]; o[(size_t)((2 * t + 1) * NL + w) * m_pts] = c.a1.v[w]; }
+        });
+    });
+}
 GPBC_KERNEL k_final_exp_wide(const uint8_t *f_in, uint8_t *gt_out, size_t n) {
     __shared__ w128 w_mem[W_SLOTS * 6];
     const size_t i = blockIdx.x;
@@ -1000,7 +1021,8 @@ int gpbc_multi_pair_fixed_q_dev(const void *dP, const void *dQ, size_t m, size_t
         int32_t *dLines = tmp.take<int32_t>(m * LINE_BYTES_PER_PAIR), *dQ34 = tmp.take<int32_t>(q34_bytes), *dPint = tmp.take<int32_t>(pint_bytes);
         uint8_t *dPart = tmp.take(part_bytes);
         HIP_TRY(hipMemsetAsync(dLines, 0, m * LINE_BYTES_PER_PAIR, st));           // rows of points at infinity are never written, but are scaled
-        k_q_lines<<<grid_for(m), BLOCK, 0, st>>>((const uint8_t *)dQ, dLines, m);
+        if (m <= g_wide_max.load() && g_wide_max.load() > 0) k_q_lines_wide<<<(unsigned)m, BLOCK, 0, st>>>((const uint8_t *)dQ, dLines, m);
+        else k_q_lines<<<grid_for(m), BLOCK, 0, st>>>((const uint8_t *)dQ, dLines, m);
         TRY(check_launch("k_q_lines"));
         profile_mark("k_q_lines", st);
         k_q_lines_scale<<<grid_for(m * MILLER_LINES), BLOCK, 0, st>>>(dLines, dQ34, m);

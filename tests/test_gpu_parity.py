@@ -296,8 +296,14 @@ def test_multi_pair_fixed_q(eng, oracle, synth):
         for chunk in (64, 24, 35):
             _lib.check(_lib.load().gpbc_set_multi_pair_chunk(chunk))
             assert (eng.multi_pair_fixed_q(Ps, Qs) == want).all(), chunk
+        # the line table of the list: one Q_i per wavefront (k_q_lines_wide, lists within the latency limit) and one per lane
+        _lib.check(_lib.load().gpbc_set_latency_path(0))
+        assert (eng.multi_pair_fixed_q(Ps, Qs) == want).all()
+        _lib.check(_lib.load().gpbc_set_multi_pair_chunk(0))
+        assert (eng.multi_pair_fixed_q(Ps, Qs) == want).all()
     finally:
         _lib.load().gpbc_set_multi_pair_chunk(0)
+        _lib.load().gpbc_set_latency_path(2048)
 
 
 def test_bls_verify_flow(eng):

@@ -634,7 +634,9 @@ int gpbc_final_exp_dev(const void *d_f, size_t n, void *d_gt_out, void *stream) 
     if (!n) return GPBC_OK;
     if (!d_f || !d_gt_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
     TRY(bind_device());
-    if (n <= g_wide_max.load()) {
+    // (two rounds of the chip still beat the lane-pair kernel's 2.6 ms floor: 3 072 / 4 096 values 1.38 / 1.75 ms; 6 144: 2.54 — even.
+    // The Miller loop's switch-over stays at one round: its wavefront form holds 768 pairings at a time.)
+    if (n <= 2 * g_wide_max.load()) {
         k_final_exp_wide<<<(unsigned)n, BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_f, (uint8_t *)d_gt_out, n);
         profile_mark("k_final_exp_wide", (hipStream_t)stream);
         return check_launch("k_final_exp_wide");

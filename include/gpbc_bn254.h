@@ -145,7 +145,7 @@ int gpbc_set_pipelined_miller(int on);
 /* The LATENCY path.  Every reference call site is ONE bn254.Pair / PairingCheck (cpabe/bsw07/bsw07_cpabe.go:184,
  * signature/bls01_signature/bls_signature.go:81, ...); in the throughput kernels one pairing is a chain of ~2 M dependent
  * instructions on one lane pair — ~6 ms per call whatever the batch size.  Calls of at most `max_pairs` Miller loops / final
- * exponentiations (default 2048: one wave per SIMD pair of the chip) run ONE PAIRING PER WAVEFRONT instead, the 64 lanes working
+ * exponentiations (default 2048: one wave per SIMD pair of the chip; final exponentiations alone up to twice that) run ONE PAIRING PER WAVEFRONT instead, the 64 lanes working
  * on the F2 products inside it (csrc/wide29.hip.hpp): same bits, about a fifth of the latency (1.2 ms per call).  The same limit
  * sends GT.Exp calls of at most 2 x `max_pairs` elements down a one-element-per-wavefront kernel (0.8 ms instead of 5 ms for one
  * new(GT).Exp, access/tree/access_tree_node.go:114), and multi-pairing calls of at most `max_pairs` pairs multiply the Miller

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised soak of the GPU engine against the C restatement (oracle/): many more inputs than the test-suite uses, to
-reach rare paths (exact zero tests, exceptional additions, large table indices).  Test infrastructure — run on a GPU box:
-    python tools/soak.py [n]        (default n = 65536)
+reach rare paths (exact zero tests, exceptional additions, large table indices).  Test infrastructure (it imports the oracle, so it
+lives under tests/; not collected by pytest) — run on a GPU box:
+    python tests/soak.py [n]        (default n = 65536)
 """
 import os
 import sys

@@ -135,13 +135,14 @@ int sync_default();
 // more (profiles/r03_size_sweep.txt: a 1.6 ms decode call measured at 12-15 ms) — so freed blocks go to a small per-device cache
 // (gpbc_core.hip: size classes, at most 1 GiB kept per device, gpbc_release_workspaces() empties it) and come back from there.
 // A block returns to the cache only after the device has drained, which is what hipFree's implicit synchronisation did.
-int dev_block_alloc(size_t bytes, void **p, size_t *cap);
-void dev_block_free(void *p, size_t cap);
+int dev_block_alloc(size_t bytes, void **p, size_t *cap, int *dev);
+void dev_block_free(void *p, size_t cap, int dev);
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
-    ~DevBuf() { if (p) dev_block_free(p, cap); }
-    int alloc(size_t bytes) { return dev_block_alloc(bytes ? bytes : 1, &p, &cap); }
+    int dev = -1;                    // the device slot the block lives on (the thread's current device at alloc())
+    ~DevBuf() { if (p) dev_block_free(p, cap, dev); }
+    int alloc(size_t bytes) { return dev_block_alloc(bytes ? bytes : 1, &p, &cap, &dev); }
     int upload(const void *src, size_t bytes) {
         TRY(alloc(bytes));
         if (bytes) HIP_TRY(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
@@ -203,5 +204,47 @@ struct Scratch {
 int pinned_staging(hipStream_t stream, size_t bytes, uint8_t **out);
 static inline int lines_workspace(hipStream_t stream, size_t pairs, int32_t **out) { return stream_workspace(stream, pairs * LINE_BYTES_PER_PAIR, out); }
 void free_workspaces();
+
+// ---- Small host-pointer calls: the reference's call shape.  Every reference call site is ONE bn254.Pair of one pair, one
+// PairingCheck of two, one ScalarMultiplication (access/tree/access_tree_node.go:106-123, signature/bls01_signature/bls_signature.go:45,81)
+// and a cgo replacement is called like that from many OS threads at once.  A lone such call is a dependent chain
+// on a handful of wavefronts; T of them side by side cost the same GPU time as one, so calls that arrive while the device is
+// busy are COMBINED: a caller enqueues its request and, if one of the device's call lanes is free, becomes the leader — it takes
+// every request of its kind that is waiting (its own among them), copies the inputs into the lane's pinned block, launches ONE
+// batch on the lane's stream, waits for that stream alone and hands each caller its slice.  Callers that arrive while all lanes
+// are busy sleep until a leader has served them or a lane is free.  No timer, no helper thread: a lone call runs at once on the
+// calling thread (nothing to wait for), a crowd rides in batches as large as the arrival rate makes them.
+// A lane = a non-blocking stream + a pinned host block that is mapped into the device (kernels read the inputs from it and
+// write the results into it: no copy engine on the path of a 192-byte call) + a device block for intermediates.  Nothing here
+// touches the null stream, the device-wide scratch lock or hipDeviceSynchronize.
+constexpr int CALL_LANES = 4;
+constexpr size_t SMALL_CALL_MAX_UNITS = 2048;       // per batch (and per call): one round of wavefronts on the chip
+enum SmallKind { CALL_PAIRS = 0, CALL_G1_MUL, CALL_G2_MUL, CALL_GT_EXP, CALL_GT_MUL, CALL_GT_DIV, CALL_GT_INV, CALL_KINDS };
+struct CallLane {
+    int device = -1;                 // index into the bound device list
+    hipStream_t stream = nullptr;
+    uint8_t *pin = nullptr, *d_pin = nullptr;       // the pinned block: host address / the device's address of the same bytes
+    size_t pin_bytes = 0;
+    uint8_t *dev = nullptr;
+    size_t dev_bytes = 0;
+    bool busy = false;
+    int reserve(size_t pin_need, size_t dev_need);  // grow-only; called by the batch runner before it writes anything
+};
+struct SmallCall {
+    const void *in[3] = {nullptr, nullptr, nullptr};   // caller's input columns (meaning per kind)
+    bool in_one[3] = {false, false, false};            // column holds ONE element for all units (a shared base)
+    void *out[2] = {nullptr, nullptr};
+    size_t units = 0;                                  // pairs / points / GT elements
+    const uint64_t *seg = nullptr;                     // CALL_PAIRS: the call's own segment table (segs + 1 entries); null = one pair per segment
+    size_t segs = 0;
+    int rc = GPBC_OK;
+    char err[512] = "";
+    bool taken = false, done = false;
+    std::condition_variable cv;
+};
+using SmallBatchFn = int (*)(CallLane &lane, SmallCall *const *calls, size_t n_calls);
+// Runs `c` through the combiner of the calling thread's current device; returns the call's status with gpbc_last_error() set.
+int small_call(SmallKind kind, SmallCall &c, SmallBatchFn run);
+void free_call_lanes();
 
 #endif

@@ -4,6 +4,7 @@
 // entry.  gfx950 only.
 #include "gpbc_common.hpp"
 #include <cstdlib>
+#include <deque>
 #include <dlfcn.h>
 #include <rccl/rccl.h>      // types and enums only: the library is opened with dlopen when a communicator is first asked for
 #include <string>
@@ -29,6 +30,11 @@ struct DeviceCtx {
     ncclComm_t comm = nullptr;    // RCCL communicator of this device (rank = comm_rank of comm_ranks), or null
     hipStream_t pipe[3] = {nullptr, nullptr, nullptr};   // large host-pointer calls: two compute streams + one download stream
     std::mutex pipe_mu;
+    // small host-pointer calls (gpbc_common.hpp): the lanes and one queue of waiting requests per kind, all under calls_mu
+    std::mutex calls_mu;
+    CallLane lanes[CALL_LANES];
+    std::deque<SmallCall *> waiting[CALL_KINDS];
+    int next_kind = 0;                                   // where the search for the next leader starts (round robin over the kinds)
 };
 static DeviceCtx g_ctx[MAX_DEVICES];
 static std::atomic<int> g_ndev{0};
@@ -120,6 +126,93 @@ int run_sharded(size_t n, size_t min_units, const std::function<int(size_t, size
     return GPBC_OK;
 }
 
+// ---- small host-pointer calls: lanes, queues, leader election (the scheme is described in gpbc_common.hpp)
+int CallLane::reserve(size_t pin_need, size_t dev_need) {
+    if (pin_need > pin_bytes) {
+        size_t want = pin_bytes ? pin_bytes : (size_t)256 << 10;
+        while (want < pin_need) want <<= 1;
+        if (pin) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipHostFree(pin)); pin = d_pin = nullptr; pin_bytes = 0; }
+        void *h = nullptr, *d = nullptr;
+        HIP_TRY(hipHostMalloc(&h, want, hipHostMallocMapped));
+        if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipHostFree(h); return fail(GPBC_ERR_HIP, "hipHostGetDevicePointer failed for a call lane's pinned block"); }
+        pin = (uint8_t *)h; d_pin = (uint8_t *)d; pin_bytes = want;
+    }
+    if (dev_need > dev_bytes) {
+        size_t want = dev_bytes ? dev_bytes : (size_t)1 << 20;
+        while (want < dev_need) want <<= 1;
+        if (dev) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(dev)); dev = nullptr; dev_bytes = 0; }
+        void *d = nullptr;
+        HIP_TRY(hipMalloc(&d, want));
+        dev = (uint8_t *)d; dev_bytes = want;
+    }
+    return GPBC_OK;
+}
+int small_call(SmallKind kind, SmallCall &c, SmallBatchFn run) {
+    const int n = g_ndev.load(), di = cur_index();
+    if (n <= 0 || di >= n) return fail(GPBC_ERR_NO_DEVICE, "gpbc_init() has not bound a HIP device (no CPU fallback exists)");
+    if (!c.units || c.units > SMALL_CALL_MAX_UNITS) return fail(GPBC_ERR_INTERNAL, "small_call: %zu units", c.units);
+    DeviceCtx &x = g_ctx[di];
+    std::unique_lock<std::mutex> lk(x.calls_mu);
+    x.waiting[kind].push_back(&c);
+    std::vector<SmallCall *> batch;
+    while (!c.done) {
+        CallLane *lane = nullptr;
+        if (!c.taken)
+            for (auto &l : x.lanes) if (!l.busy) { lane = &l; break; }
+        if (!lane) { c.cv.wait(lk); continue; }           // a leader is serving this call, or every lane is busy: woken when served / when a lane is free
+        // leader: everything of this kind that is waiting, oldest first, up to one round of the chip
+        auto &q = x.waiting[kind];
+        batch.clear();
+        size_t units = 0;
+        while (!q.empty() && (batch.empty() || units + q.front()->units <= SMALL_CALL_MAX_UNITS)) {
+            units += q.front()->units;
+            q.front()->taken = true;
+            batch.push_back(q.front());
+            q.pop_front();
+        }
+        lane->busy = true;
+        lane->device = di;
+        lk.unlock();
+        int rc = GPBC_OK;
+        if (!lane->stream && hipStreamCreateWithFlags(&lane->stream, hipStreamNonBlocking) != hipSuccess) rc = fail(GPBC_ERR_HIP, "hipStreamCreateWithFlags failed for a call lane");
+        if (rc == GPBC_OK) rc = run(*lane, batch.data(), batch.size());
+        if (rc != GPBC_OK && lane->stream) (void)hipStreamSynchronize(lane->stream);      // nothing of a failed batch may still be running when the lane is reused
+        lk.lock();
+        lane->busy = false;
+        for (SmallCall *b : batch) {
+            if (rc != GPBC_OK && b->rc == GPBC_OK) { b->rc = rc; snprintf(b->err, sizeof b->err, "%s", g_err); }
+            b->done = true;
+            if (b != &c) b->cv.notify_one();
+        }
+        // lanes are free: the oldest waiting request of each kind may lead next (one per free lane, kinds in turn)
+        int free_lanes = 0;
+        for (auto &l : x.lanes) free_lanes += l.busy ? 0 : 1;
+        for (int t = 0; t < CALL_KINDS && free_lanes > 0; t++) {
+            const int k2 = (x.next_kind + t) % CALL_KINDS;
+            if (!x.waiting[k2].empty()) { x.waiting[k2].front()->cv.notify_one(); free_lanes--; }
+        }
+        x.next_kind = (x.next_kind + 1) % CALL_KINDS;
+    }
+    if (c.rc != GPBC_OK) return fail(c.rc, "%s", c.err);
+    return GPBC_OK;
+}
+void free_call_lanes() {
+    int keep = -1;
+    (void)hipGetDevice(&keep);
+    for (int i = 0; i < MAX_DEVICES; i++) {
+        std::lock_guard<std::mutex> lk(g_ctx[i].calls_mu);
+        for (auto &l : g_ctx[i].lanes) {
+            if (!l.stream && !l.pin && !l.dev) continue;
+            if (g_ctx[i].hip >= 0) (void)hipSetDevice(g_ctx[i].hip);
+            if (l.stream) { (void)hipStreamSynchronize(l.stream); (void)hipStreamDestroy(l.stream); }
+            if (l.pin) (void)hipHostFree(l.pin);
+            if (l.dev) (void)hipFree(l.dev);
+            l = CallLane();
+        }
+    }
+    if (keep >= 0) (void)hipSetDevice(keep);
+}
+
 // ---- internal workspace, one grow-only buffer per (bound device slot, stream)
 struct StreamWs { int device; hipStream_t stream; int kind; void *ptr; size_t bytes; };      // device = index into g_ctx; kind 0 = workspace, 1 + level = scratch, KIND_PINNED = pinned host staging
 constexpr int KIND_PINNED = 100;
@@ -127,6 +220,7 @@ static hipError_t ws_alloc(int kind, void **p, size_t bytes) { return kind == KI
 static hipError_t ws_free(int kind, void *p) { return kind == KIND_PINNED ? hipHostFree(p) : hipFree(p); }
 static std::mutex g_ws_mu;
 static std::vector<StreamWs> g_ws;
+void free_device_blocks();
 static int stream_buffer(int kind, hipStream_t stream, size_t bytes, void **out) {
     int dev = cur_index();
     std::lock_guard<std::mutex> lk(g_ws_mu);
@@ -136,14 +230,14 @@ static int stream_buffer(int kind, hipStream_t stream, size_t bytes, void **out)
                 HIP_TRY(hipStreamSynchronize(stream));
                 HIP_TRY(ws_free(kind, w.ptr));
                 w.ptr = nullptr; w.bytes = 0;
-                HIP_TRY(ws_alloc(kind, &w.ptr, bytes));
+                if (ws_alloc(kind, &w.ptr, bytes) != hipSuccess) { w.ptr = nullptr; free_device_blocks(); HIP_TRY(ws_alloc(kind, &w.ptr, bytes)); }
                 w.bytes = bytes;
             }
             *out = w.ptr;
             return GPBC_OK;
         }
     void *ptr = nullptr;
-    HIP_TRY(ws_alloc(kind, &ptr, bytes));
+    if (ws_alloc(kind, &ptr, bytes) != hipSuccess) { free_device_blocks(); HIP_TRY(ws_alloc(kind, &ptr, bytes)); }   // the block cache may hold what is missing
     g_ws.push_back(StreamWs{dev, stream, kind, ptr, bytes});
     *out = ptr;
     return GPBC_OK;
@@ -165,9 +259,10 @@ static size_t blk_class(size_t bytes) {
     while (c < bytes) c <<= 1;
     return c;
 }
-int dev_block_alloc(size_t bytes, void **p, size_t *cap) {
+int dev_block_alloc(size_t bytes, void **p, size_t *cap, int *dev_out) {
     const size_t c = blk_class(bytes);
     const int dev = cur_index();
+    *dev_out = dev;
     {
         std::lock_guard<std::mutex> lk(g_blk_mu);
         for (size_t i = 0; i < g_blk.size(); i++)
@@ -187,9 +282,15 @@ int dev_block_alloc(size_t bytes, void **p, size_t *cap) {
     *cap = c;
     return GPBC_OK;
 }
-void dev_block_free(void *p, size_t cap) {
-    const int dev = cur_index();
-    (void)hipDeviceSynchronize();                             // nothing in flight may still use the block (what hipFree guarantees)
+void dev_block_free(void *p, size_t cap, int dev) {
+    // `dev` = the device slot the block was allocated on (DevBuf remembers it: the thread may have switched since).  Nothing in
+    // flight THERE may still use the block — what hipFree guarantees — so that device is drained, whichever one is current.
+    int keep = -1;
+    (void)hipGetDevice(&keep);
+    const int owner = (dev >= 0 && dev < MAX_DEVICES) ? g_ctx[dev].hip : -1;
+    if (owner >= 0 && owner != keep) (void)hipSetDevice(owner);
+    (void)hipDeviceSynchronize();
+    struct Restore { int keep, owner; ~Restore() { if (owner >= 0 && keep >= 0 && owner != keep) (void)hipSetDevice(keep); } } restore{keep, owner};
     {
         std::lock_guard<std::mutex> lk(g_blk_mu);
         if (dev >= 0 && dev < MAX_DEVICES && g_blk_bytes[dev] + cap <= BLK_KEEP_PER_DEVICE) {
@@ -211,6 +312,7 @@ void free_device_blocks() {
 }
 void free_workspaces() {
     free_device_blocks();
+    free_call_lanes();
     std::lock_guard<std::mutex> lk(g_ws_mu);
     for (auto &w : g_ws) if (w.ptr) { if (g_ctx[w.device].hip >= 0) (void)hipSetDevice(g_ctx[w.device].hip); (void)ws_free(w.kind, w.ptr); }
     g_ws.clear();

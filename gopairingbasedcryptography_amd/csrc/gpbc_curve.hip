@@ -286,9 +286,43 @@ int gpbc_g1_sum_dev(const void *p, size_t n, void *o, void *w, size_t wb, void *
 int gpbc_g2_sum_dev(const void *p, size_t n, void *o, void *w, size_t wb, void *s) { return sum_dev(true, p, n, o, w, wb, s); }
 
 constexpr size_t SMUL_PIPE_CHUNK = 131072;
+// Small calls (gpbc_common.hpp "Small host-pointer calls"): every waiting ScalarMultiplication of one group in one launch of the
+// quad-of-lanes kernel on a call lane — bases and scalars read from the lane's pinned block, results written into it, the GLV
+// tables in the lane's device block.  A call with one base for all its scalars gets that base repeated per scalar.
+static int small_mul_run(bool G2, CallLane &lane, SmallCall *const *calls, size_t nc) {
+    const size_t pt = G2 ? GPBC_G2_BYTES : GPBC_G1_BYTES;
+    const size_t tab_bytes = sizeof(int32_t) * (G2 ? (size_t)glv_table_dwords<F2>() : (size_t)glv_table_dwords<Fe>());
+    size_t N = 0;
+    for (size_t c = 0; c < nc; c++) N += calls[c]->units;
+    const size_t oB = 0, oS = Scratch::padded(N * pt), oO = oS + Scratch::padded(N * GPBC_SCALAR_BYTES), total = oO + Scratch::padded(N * pt);
+    TRY(lane.reserve(total, N * tab_bytes));
+    size_t n0 = 0;
+    for (size_t c = 0; c < nc; c++) {
+        const SmallCall &r = *calls[c];
+        if (r.in_one[0]) for (size_t i = 0; i < r.units; i++) memcpy(lane.pin + oB + (n0 + i) * pt, r.in[0], pt);
+        else memcpy(lane.pin + oB + n0 * pt, r.in[0], r.units * pt);
+        memcpy(lane.pin + oS + n0 * GPBC_SCALAR_BYTES, r.in[1], r.units * GPBC_SCALAR_BYTES);
+        n0 += r.units;
+    }
+    if (G2) k_g2_scalar_mul_quad<<<grid_for(4 * N), BLOCK, 0, lane.stream>>>(lane.d_pin + oB, 0, lane.d_pin + oS, lane.d_pin + oO, N, (int32_t *)lane.dev);
+    else k_g1_scalar_mul_quad<<<grid_for(4 * N), BLOCK, 0, lane.stream>>>(lane.d_pin + oB, 0, lane.d_pin + oS, lane.d_pin + oO, N, (int32_t *)lane.dev);
+    TRY(check_launch(G2 ? "k_g2_scalar_mul_quad" : "k_g1_scalar_mul_quad"));
+    profile_mark(G2 ? "k_g2_scalar_mul_quad" : "k_g1_scalar_mul_quad", lane.stream);
+    HIP_TRY(hipStreamSynchronize(lane.stream));
+    n0 = 0;
+    for (size_t c = 0; c < nc; c++) { memcpy(calls[c]->out[0], lane.pin + oO + n0 * pt, calls[c]->units * pt); n0 += calls[c]->units; }
+    return GPBC_OK;
+}
+static int small_g1_mul_run(CallLane &l, SmallCall *const *c, size_t n) { return small_mul_run(false, l, c, n); }
+static int small_g2_mul_run(CallLane &l, SmallCall *const *c, size_t n) { return small_mul_run(true, l, c, n); }
 static int scalar_mul_one(bool g2, const void *bases, size_t nbase, const void *scalars, size_t n, void *out) {
     TRY(bind_device());
     size_t pt = g2 ? GPBC_G2_BYTES : GPBC_G1_BYTES;
+    if (n <= SMALL_CALL_MAX_UNITS) {
+        SmallCall c;
+        c.in[0] = bases; c.in_one[0] = nbase == 1 && n != 1; c.in[1] = scalars; c.out[0] = out; c.units = n;
+        return g2 ? small_call(CALL_G2_MUL, c, small_g2_mul_run) : small_call(CALL_G1_MUL, c, small_g1_mul_run);
+    }
     if (nbase == n && n >= 2 * SMUL_PIPE_CHUNK) {
         // one base per scalar, large batch: transfers of neighbouring chunks overlap the kernels (pipelined_chunks)
         DevBuf dB, dS, dO;

@@ -408,8 +408,10 @@ GPBC_KERNEL k_segment_fold_wide(uint8_t *f, const uint64_t *__restrict__ seg_off
 // of the table and the same echo (first value, values consumed) as k_segment_product.
 // `fold` > 0: k_segment_fold_wide ran first with that many residue classes, so the segment's product is the product of its first
 // `fold` values.
+// `ok_out` (may be null): 1 where the segment's value is GT's one — PairingCheck's answer, taken from the canonical words the lanes
+// are about to store (a later k_gt_is_one would have to read them back, and in a small call they live in host memory).
 GPBC_KERNEL k_segment_final_exp_wide(const uint8_t *__restrict__ f, const uint64_t *__restrict__ seg_off, size_t uniform_len, uint8_t *__restrict__ out, size_t k, size_t n_vals,
-                                     uint64_t *__restrict__ echo, unsigned fold) {
+                                     uint64_t *__restrict__ echo, unsigned fold, uint8_t *__restrict__ ok_out) {
     __shared__ w128 w_mem[W_SLOTS * 6];
     const size_t j = blockIdx.x;
     if (j >= k) return;
@@ -425,7 +427,20 @@ GPBC_KERNEL k_segment_final_exp_wide(const uint8_t *__restrict__ f, const uint64
         wide_mul(m, wv(0), wv(0), wv(1));
     }
     wide_final_exp(m);
-    m.run(6, [&](int c) { f2_store(out + j * GPBC_GT_BYTES + 64 * c, m.ld(c)); });
+    uint32_t diff = 0;
+    if (threadIdx.x < 6) {
+        const F2 v = m.ld((int)threadIdx.x);
+        uint32_t w[16];
+        fe_to_words(w, v.a0); fe_to_words(w + 8, v.a1);
+        uint32_t *o = reinterpret_cast<uint32_t *>(out + j * GPBC_GT_BYTES + 64 * threadIdx.x);
+        constexpr uint64_t ONE[4] = BN254_FP_ONE;
+#pragma unroll
+        for (int t = 0; t < 16; t++) { o[t] = w[t]; diff |= w[t] ^ ((threadIdx.x == 0 && t < 8) ? (uint32_t)(ONE[t >> 1] >> ((t & 1) * 32)) : 0u); }
+    }
+    if (ok_out) {
+        const bool one = __builtin_amdgcn_ballot_w64(diff != 0) == 0;       // lanes 6..63 carry diff = 0
+        if (threadIdx.x == 0) ok_out[j] = one ? 1 : 0;
+    }
     if (echo && threadIdx.x == 0) { echo[2 * j] = lo; echo[2 * j + 1] = hi - lo; }
 }
 
@@ -584,7 +599,8 @@ int gpbc_set_pipelined_miller(int on) { g_pipelined.store(on == 2 ? 2 : on ? 1 :
 constexpr size_t WIDE_DEFAULT_MAX_PAIRS = 2048;
 static std::atomic<size_t> g_wide_max{WIDE_DEFAULT_MAX_PAIRS};
 int gpbc_set_latency_path(long max_pairs) {
-    if (max_pairs < 0) return fail(GPBC_ERR_INVALID_ARG, "max_pairs must be >= 0 (0 = off)");
+    // (the wavefront forms launch one workgroup per pairing or per segment chunk: the limit keeps every such grid far inside 2^31)
+    if (max_pairs < 0 || max_pairs > 65536) return fail(GPBC_ERR_INVALID_ARG, "max_pairs must be 0 (off) .. 65536");
     g_wide_max.store((size_t)max_pairs);
     return GPBC_OK;
 }
@@ -672,14 +688,14 @@ static int segment_fold_passes(uint8_t *vals, const uint64_t *d_seg_off, size_t 
     return GPBC_OK;
 }
 // latency path, after the Miller loop: the values of each segment (table, or equal runs of `uniform_len`) multiplied and exponentiated
-static int segments_wide(uint8_t *vals, const uint64_t *d_seg_off, size_t uniform_len, size_t k, size_t n_vals, uint8_t *d_gt_out, uint64_t *d_echo, hipStream_t st) {
+static int segments_wide(uint8_t *vals, const uint64_t *d_seg_off, size_t uniform_len, size_t k, size_t n_vals, uint8_t *d_gt_out, uint64_t *d_echo, hipStream_t st, uint8_t *d_ok = nullptr) {
     const unsigned fold = n_vals >= 128 * k ? 16u : n_vals >= 32 * k ? 8u : 0u;
     if (fold) {
         k_segment_fold_wide<<<(unsigned)(k * fold), BLOCK, 0, st>>>(vals, d_seg_off, uniform_len, k, n_vals, fold);
         TRY(check_launch("k_segment_fold_wide"));
         profile_mark("k_segment_fold_wide", st);
     }
-    k_segment_final_exp_wide<<<(unsigned)k, BLOCK, 0, st>>>(vals, d_seg_off, uniform_len, d_gt_out, k, n_vals, d_echo, fold);
+    k_segment_final_exp_wide<<<(unsigned)k, BLOCK, 0, st>>>(vals, d_seg_off, uniform_len, d_gt_out, k, n_vals, d_echo, fold, d_ok);
     TRY(check_launch("k_segment_final_exp_wide"));
     profile_mark("k_segment_final_exp_wide", st);
     return GPBC_OK;
@@ -796,6 +812,91 @@ int gpbc_final_exp(const void *f, size_t n, void *gt_out) {
         return final_exp_one((const uint8_t *)f + lo * GPBC_GT_BYTES, hi - lo, (uint8_t *)gt_out + lo * GPBC_GT_BYTES);
     });
 }
+// ---- small calls (gpbc_common.hpp "Small host-pointer calls"): every waiting Pair / PairingCheck / multi-pairing of the latency
+// path in ONE launch pair on a call lane.  The batch is a multi-pairing over the concatenated pairs with the concatenated segment
+// table (a pair_batch call contributes one segment per pair); k_miller_wide reads P and Q straight from the lane's pinned block,
+// k_segment_final_exp_wide writes the GT values, the PairingCheck flags and the echo of the table straight into it.
+static std::atomic<int> g_fault_table{0};
+static int verify_echo(const uint64_t *echo, const uint64_t *seg_off, size_t k);
+static int small_pairs_run(CallLane &lane, SmallCall *const *calls, size_t nc) {
+    size_t N = 0, K = 0;
+    for (size_t c = 0; c < nc; c++) { N += calls[c]->units; K += calls[c]->segs; }
+    const size_t oP = 0, oQ = oP + Scratch::padded(N * GPBC_G1_BYTES), oSeg = oQ + Scratch::padded(N * GPBC_G2_BYTES), oEcho = oSeg + Scratch::padded((K + 1) * sizeof(uint64_t)),
+                 oGt = oEcho + Scratch::padded(2 * K * sizeof(uint64_t)), oOk = oGt + Scratch::padded(K * GPBC_GT_BYTES), total = oOk + Scratch::padded(K);
+    TRY(lane.reserve(total, N * GPBC_GT_BYTES));
+    std::vector<uint64_t> table(K + 1);                          // what the host says; the device answers with what it consumed
+    size_t n0 = 0, k0 = 0;
+    for (size_t c = 0; c < nc; c++) {
+        const SmallCall &r = *calls[c];
+        memcpy(lane.pin + oP + n0 * GPBC_G1_BYTES, r.in[0], r.units * GPBC_G1_BYTES);
+        memcpy(lane.pin + oQ + n0 * GPBC_G2_BYTES, r.in[1], r.units * GPBC_G2_BYTES);
+        for (size_t j = 0; j < r.segs; j++) table[k0 + j] = n0 + (r.seg ? r.seg[j] : j);
+        n0 += r.units; k0 += r.segs;
+    }
+    table[K] = N;
+    uint64_t *pin_seg = (uint64_t *)(lane.pin + oSeg), *h_echo = (uint64_t *)(lane.pin + oEcho);
+    memcpy(pin_seg, table.data(), (K + 1) * sizeof(uint64_t));
+    if (g_fault_table.exchange(0)) pin_seg[K] = pin_seg[K - 1];  // test knob: the device sees a last segment that is empty
+    memset(h_echo, 0xff, 2 * K * sizeof(uint64_t));
+    k_miller_wide<<<(unsigned)N, WIDE_MILLER_THREADS, 0, lane.stream>>>(lane.d_pin + oP, lane.d_pin + oQ, lane.dev, N, 0);
+    TRY(check_launch("k_miller_wide"));
+    profile_mark("k_miller_wide", lane.stream);
+    TRY(segments_wide(lane.dev, (const uint64_t *)(lane.d_pin + oSeg), 0, K, N, lane.d_pin + oGt, (uint64_t *)(lane.d_pin + oEcho), lane.stream, lane.d_pin + oOk));
+    HIP_TRY(hipStreamSynchronize(lane.stream));
+    k0 = 0;
+    for (size_t c = 0; c < nc; c++) {
+        SmallCall &r = *calls[c];
+        // fail closed, call by call: a result computed from a table that was not the caller's does not leave the library
+        const int rc = verify_echo(h_echo + 2 * k0, table.data() + k0, r.segs);
+        if (rc != GPBC_OK) {
+            r.rc = rc; snprintf(r.err, sizeof r.err, "%s", g_err);
+            if (r.out[0]) memset(r.out[0], 0, r.segs * GPBC_GT_BYTES);
+            if (r.out[1]) memset(r.out[1], 0, r.segs);
+        } else {
+            if (r.out[0]) memcpy(r.out[0], lane.pin + oGt + k0 * GPBC_GT_BYTES, r.segs * GPBC_GT_BYTES);
+            if (r.out[1]) memcpy(r.out[1], lane.pin + oOk + k0, r.segs);
+        }
+        k0 += r.segs;
+    }
+    return GPBC_OK;
+}
+// GT.Exp / Mul / Div / Inverse one call at a time (access/tree/access_tree_node.go:114,123,156-157): elementwise batches on a lane
+static int small_gt_run(int OP, CallLane &lane, SmallCall *const *calls, size_t nc) {     // OP 0 mul, 1 div, 2 inverse, 3 exp
+    size_t N = 0;
+    for (size_t c = 0; c < nc; c++) N += calls[c]->units;
+    const size_t b_unit = OP == 3 ? GPBC_SCALAR_BYTES : OP == 2 ? 0 : GPBC_GT_BYTES;
+    const size_t oA = 0, oB = Scratch::padded(N * GPBC_GT_BYTES), oO = oB + Scratch::padded(N * b_unit), total = oO + Scratch::padded(N * GPBC_GT_BYTES);
+    TRY(lane.reserve(total, OP == 3 ? 0 : 2 * N * GPBC_GT_BYTES));
+    size_t n0 = 0;
+    for (size_t c = 0; c < nc; c++) {
+        const SmallCall &r = *calls[c];
+        memcpy(lane.pin + oA + n0 * GPBC_GT_BYTES, r.in[0], r.units * GPBC_GT_BYTES);
+        if (b_unit) memcpy(lane.pin + oB + n0 * b_unit, r.in[1], r.units * b_unit);
+        n0 += r.units;
+    }
+    if (OP == 3) {
+        k_gt_exp_wide<<<(unsigned)N, BLOCK, 0, lane.stream>>>(lane.d_pin + oA, lane.d_pin + oB, lane.d_pin + oO, N);
+        TRY(check_launch("k_gt_exp_wide"));
+        profile_mark("k_gt_exp_wide", lane.stream);
+    } else {
+        // one lane per element walks its 384 + 384 bytes many times: operands into device memory first
+        HIP_TRY(hipMemcpyAsync(lane.dev, lane.pin + oA, N * GPBC_GT_BYTES, hipMemcpyHostToDevice, lane.stream));
+        if (b_unit) HIP_TRY(hipMemcpyAsync(lane.dev + N * GPBC_GT_BYTES, lane.pin + oB, N * GPBC_GT_BYTES, hipMemcpyHostToDevice, lane.stream));
+        k_gt_binary<<<grid_for(N), BLOCK, 0, lane.stream>>>(lane.dev, lane.dev + N * GPBC_GT_BYTES, lane.d_pin + oO, N, OP);
+        TRY(check_launch("k_gt_binary"));
+        profile_mark("k_gt_binary", lane.stream);
+    }
+    HIP_TRY(hipStreamSynchronize(lane.stream));
+    n0 = 0;
+    for (size_t c = 0; c < nc; c++) { memcpy(calls[c]->out[0], lane.pin + oO + n0 * GPBC_GT_BYTES, calls[c]->units * GPBC_GT_BYTES); n0 += calls[c]->units; }
+    return GPBC_OK;
+}
+static int small_gt_mul_run(CallLane &l, SmallCall *const *c, size_t n) { return small_gt_run(0, l, c, n); }
+static int small_gt_div_run(CallLane &l, SmallCall *const *c, size_t n) { return small_gt_run(1, l, c, n); }
+static int small_gt_inv_run(CallLane &l, SmallCall *const *c, size_t n) { return small_gt_run(2, l, c, n); }
+static int small_gt_exp_run(CallLane &l, SmallCall *const *c, size_t n) { return small_gt_run(3, l, c, n); }
+static bool small_call_ok(size_t units) { const size_t lim = g_wide_max.load(); return units && units <= lim && units <= SMALL_CALL_MAX_UNITS; }
+
 constexpr size_t PIPE_CHUNK = 131072;          // pairs per pipelined chunk: 2.5 GB of lines per stream
 static int pair_batch_one(const void *P, const void *Q, size_t n, void *gt_out) {
     TRY(bind_device());
@@ -819,16 +920,12 @@ static int pair_batch_one(const void *P, const void *Q, size_t n, void *gt_out) 
         if (rc != GPBC_OK) { (void)hipDeviceSynchronize(); return rc; }     // nothing may still use the buffers when they are freed
         return GPBC_OK;
     }
-    if (n <= g_wide_max.load()) {
-        // a latency call: its buffers come from the stream's scratch (level 3: the entries below use 0..2), not from six hipMalloc / hipFree
-        Scratch io;
-        TRY(io.open(nullptr, 3, Scratch::padded(n * GPBC_G1_BYTES) + Scratch::padded(n * GPBC_G2_BYTES) + Scratch::padded(n * GPBC_GT_BYTES)));
-        uint8_t *dP = io.take(n * GPBC_G1_BYTES), *dQ = io.take(n * GPBC_G2_BYTES), *dG = io.take(n * GPBC_GT_BYTES);
-        HIP_TRY(hipMemcpy(dP, P, n * GPBC_G1_BYTES, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(dQ, Q, n * GPBC_G2_BYTES, hipMemcpyHostToDevice));
-        TRY(gpbc_pair_batch_dev(dP, dQ, n, dG, nullptr));
-        HIP_TRY(hipMemcpy(gt_out, dG, n * GPBC_GT_BYTES, hipMemcpyDeviceToHost));       // (synchronises the null stream; the scratch lock is held until here)
-        return GPBC_OK;
+    if (small_call_ok(n)) {
+        // a latency call (bn254.Pair as the reference makes it): through the device's call lanes, combined with whatever other
+        // threads are asking for at the same moment
+        SmallCall c;
+        c.in[0] = P; c.in[1] = Q; c.out[0] = gt_out; c.units = n; c.segs = n;
+        return small_call(CALL_PAIRS, c, small_pairs_run);
     }
     DevBuf dP, dQ, dG;
     TRY(dP.upload(P, n * GPBC_G1_BYTES)); TRY(dQ.upload(Q, n * GPBC_G2_BYTES)); TRY(dG.alloc(n * GPBC_GT_BYTES));
@@ -872,8 +969,13 @@ int gpbc_set_multi_pair_chunk(int pairs_per_chunk) {
 // consumed and the call FAILS (GPBC_ERR_INTERNAL, outputs zeroed) unless that equals the host's table segment by segment.
 // test knob: the NEXT host-table multi-pairing sends the device a table whose last segment is empty while the host keeps the real
 // one — what a stale or unordered table copy looks like to the kernels; the call must then fail (tests/cpp/test_bls_flow.cpp)
-static std::atomic<int> g_fault_table{0};
-int gpbc_debug_stale_table_once(void) { g_fault_table.store(1); return GPBC_OK; }
+int gpbc_debug_stale_table_once(void) {
+    // a fault-injection knob has no business in a production process: it answers only where the environment asks for it
+    const char *e = getenv("GPBC_TEST_KNOBS");
+    if (!e || e[0] != '1') return fail(GPBC_ERR_INVALID_ARG, "test knobs are off (set GPBC_TEST_KNOBS=1 in the environment of a test process)");
+    g_fault_table.store(1);
+    return GPBC_OK;
+}
 static int verify_echo(const uint64_t *echo, const uint64_t *seg_off, size_t k) {
     for (size_t j = 0; j < k; j++) {
         const uint64_t want = seg_off[j + 1] - seg_off[j];
@@ -1070,17 +1172,11 @@ int gpbc_multi_pair_hostseg_dev(const void *dP, const void *dQ, const uint64_t *
 }
 static int multi_pair_host_one(const void *P, const void *Q, const uint64_t *seg_off, size_t k, size_t n_pairs, void *gt_out, uint8_t *ok_out) {
     TRY(bind_device());
-    if (k <= g_wide_max.load() && n_pairs <= g_wide_max.load() && n_pairs) {
-        // a latency call (Pair / PairingCheck as the reference makes them): buffers from the stream's scratch, level 3
-        Scratch io;
-        TRY(io.open(nullptr, 3, Scratch::padded(n_pairs * GPBC_G1_BYTES) + Scratch::padded(n_pairs * GPBC_G2_BYTES) + Scratch::padded(k * GPBC_GT_BYTES) + Scratch::padded(k)));
-        uint8_t *dP = io.take(n_pairs * GPBC_G1_BYTES), *dQ = io.take(n_pairs * GPBC_G2_BYTES), *dG = io.take(k * GPBC_GT_BYTES), *dOk = io.take(k);
-        HIP_TRY(hipMemcpy(dP, P, n_pairs * GPBC_G1_BYTES, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(dQ, Q, n_pairs * GPBC_G2_BYTES, hipMemcpyHostToDevice));
-        TRY(multi_pair_core(dP, dQ, seg_off, k, n_pairs, dG, ok_out ? dOk : nullptr, nullptr));
-        if (gt_out) HIP_TRY(hipMemcpy(gt_out, dG, k * GPBC_GT_BYTES, hipMemcpyDeviceToHost));
-        if (ok_out) HIP_TRY(hipMemcpy(ok_out, dOk, k, hipMemcpyDeviceToHost));
-        return GPBC_OK;
+    if (small_call_ok(n_pairs) && small_call_ok(k) && g_multi_chunk.load() <= 0) {
+        // a latency call (Pair / PairingCheck as the reference makes them): through the call lanes (small_pairs_run)
+        SmallCall c;
+        c.in[0] = P; c.in[1] = Q; c.out[0] = gt_out; c.out[1] = ok_out; c.units = n_pairs; c.seg = seg_off; c.segs = k;
+        return small_call(CALL_PAIRS, c, small_pairs_run);
     }
     DevBuf dP, dQ, dG, dOk;
     TRY(dP.upload(P, n_pairs * GPBC_G1_BYTES)); TRY(dQ.upload(Q, n_pairs * GPBC_G2_BYTES));
@@ -1117,6 +1213,11 @@ int gpbc_pairing_check(const void *P, const void *Q, const uint64_t *seg_off, si
 }
 static int gt_exp_one(const void *x, const void *k, size_t n, void *out) {
     TRY(bind_device());
+    if (small_call_ok(n)) {
+        SmallCall c;
+        c.in[0] = x; c.in[1] = k; c.out[0] = out; c.units = n;
+        return small_call(CALL_GT_EXP, c, small_gt_exp_run);
+    }
     DevBuf dX, dK, dO;
     TRY(dX.upload(x, n * GPBC_GT_BYTES)); TRY(dK.upload(k, n * GPBC_SCALAR_BYTES)); TRY(dO.alloc(n * GPBC_GT_BYTES));
     TRY(gpbc_gt_exp_batch_dev(dX.p, dK.p, n, dO.p, nullptr));
@@ -1132,6 +1233,11 @@ int gpbc_gt_exp_batch(const void *x, const void *k, size_t n, void *out) {
 }
 static int gt_binary_one(int op, const void *a, const void *b, size_t n, void *out) {
     TRY(bind_device());
+    if (small_call_ok(n)) {
+        SmallCall c;
+        c.in[0] = a; c.in[1] = b; c.out[0] = out; c.units = n;
+        return op == 0 ? small_call(CALL_GT_MUL, c, small_gt_mul_run) : op == 1 ? small_call(CALL_GT_DIV, c, small_gt_div_run) : small_call(CALL_GT_INV, c, small_gt_inv_run);
+    }
     DevBuf dA, dB, dO;
     TRY(dA.upload(a, n * GPBC_GT_BYTES));
     if (op != 2) TRY(dB.upload(b, n * GPBC_GT_BYTES));

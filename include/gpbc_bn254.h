@@ -151,12 +151,14 @@ int gpbc_set_pipelined_miller(int on);
  * new(GT).Exp, access/tree/access_tree_node.go:114), and multi-pairing calls of at most `max_pairs` pairs multiply the Miller
  * values of long segments on 8 or 16 wavefronts each (one 513-pair Pair: 1.5 ms).  0 switches the path off (tests compare the
  * two forms). */
-int gpbc_set_latency_path(long max_pairs);
+int gpbc_set_latency_path(long max_pairs);      /* 0 .. 65 536 */
 /* Fail-closed self-check of the host-table multi-pairings (gpbc_multi_pair, gpbc_pairing_check, gpbc_multi_pair_hostseg_dev): the
  * segment / chunk tables travel through library-owned pinned memory, the kernels echo the pairs they consumed per segment, and
  * the call returns GPBC_ERR_INTERNAL with zeroed outputs unless the echo equals the caller's table — a product over fewer pairs
  * than were passed (an empty product is GT one, i.e. "PairingCheck = true") can never come back as a result.  Test knob: the next
- * such call sends the device a table whose last segment is empty (what a stale table looks like) and must fail. */
+ * such call sends the device a table whose last segment is empty (what a stale table looks like) and must fail.  The knob answers
+ * only in a process whose environment has GPBC_TEST_KNOBS=1 (GPBC_ERR_INVALID_ARG otherwise): no thread of a production process
+ * can make another thread's verification fail. */
 int gpbc_debug_stale_table_once(void);
 
 /* bn254.PairingCheck(P, Q) (bool, error), k times (signature/bls01_signature/bls_signature.go:81):

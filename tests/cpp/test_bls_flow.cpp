@@ -3,6 +3,7 @@
 // plus the wrong-message / wrong-key negatives.  The message point is the real hash, bn254.HashToG2(msg, dst) with the
 // reference's DST (hash/hash_to.go:204-210), computed on the device; bls_signature.go:58-89.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include "gpbc_bn254.hpp"
@@ -41,6 +42,7 @@ static bool Verify(const G1Affine &pk, const std::string &m, const G2Affine &sig
 #define EXPECT(c) do { if (!(c)) { printf("FAIL line %d: %s\n", __LINE__, #c); return 1; } } while (0)
 
 int main() {
+    setenv("GPBC_TEST_KNOBS", "1", 1);          // this is a test process: the fault-injection knob answers only with this set
     Init(0);
     KeyPair a = KeyGenerate(1), b = KeyGenerate(2);
     G2Affine sig = Sign(a.sk, "hello pairing");

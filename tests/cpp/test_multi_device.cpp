@@ -27,6 +27,7 @@ template <class T> static bool same(const std::vector<T> &a, const std::vector<T
 }
 
 int main() {
+    setenv("GPBC_TEST_KNOBS", "1", 1);          // this is a test process: the fault-injection knob answers only with this set
     const int visible = gpbc_device_count();
     EXPECT(visible >= 1);
     std::vector<int> devs;

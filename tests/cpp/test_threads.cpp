@@ -46,6 +46,49 @@ int main() {
     int total = 0;
     for (int t = 0; t < T; t++) total += bad[t];
     if (total) { printf("FAIL: %d mismatches under concurrency\n", total); return 1; }
+
+    // The reference's call shape (access/tree/access_tree_node.go:106-123, signature/bls01_signature/bls_signature.go:45,81): 64 OS
+    // threads, each making ONE-element calls in a loop — Pair of one pair, PairingCheck of two, one ScalarMultiplication in G1 and
+    // G2, one GT.Exp / Mul / Div.  The library combines whatever is waiting into one launch per kind (csrc/gpbc_common.hpp "Small
+    // host-pointer calls"); every caller must get the bytes of its own call, i.e. what the sequential calls above returned.
+    const int T2 = 64, REPS = 6;
+    std::vector<std::thread> th2;
+    std::vector<int> bad2(T2, 0);
+    // sequential references for the derived values
+    std::vector<GT> wantMul(T), wantDiv(T), wantExp(T);
+    std::vector<G2Affine> wantQ(T);
+    for (int t = 0; t < T; t++) {
+        wantMul[t].Mul(want[t][0], want[t][1]);
+        wantDiv[t].Div(want[t][0], want[t][1]);
+        wantExp[t].Exp(want[t][2], ks[t][3]);
+        wantQ[t] = G2ScalarMultiplicationBatch({Q[t][4]}, {ks[t][5]})[0];
+    }
+    for (int u = 0; u < T2; u++)
+        th2.emplace_back([&, u] {
+            const int t = u % T;
+            for (int rep = 0; rep < REPS; rep++) {
+                const int i = (u * 7 + rep * 13) % N;
+                GT e = Pair({P[t][i]}, {Q[t][i]});
+                if (!e.Equal(want[t][i])) bad2[u]++;
+                G1Affine neg; neg.Neg(P[t][i]);
+                if (!PairingCheck({P[t][i], neg}, {Q[t][i], Q[t][i]})) bad2[u]++;          // e(P,Q) e(-P,Q) = 1
+                if (PairingCheck({P[t][i], P[t][i]}, {Q[t][i], Q[t][i]})) bad2[u]++;         // e(P,Q)^2 != 1
+                G1Affine r; r.ScalarMultiplication(P[t][i], ks[t][i]);
+                if (!r.Equal(wantP[t][i])) bad2[u]++;
+                G2Affine q; q.ScalarMultiplication(Q[t][4], ks[t][5]);
+                if (!q.Equal(wantQ[t])) bad2[u]++;
+                GT m; m.Mul(want[t][0], want[t][1]);
+                if (!m.Equal(wantMul[t])) bad2[u]++;
+                GT d; d.Div(want[t][0], want[t][1]);
+                if (!d.Equal(wantDiv[t])) bad2[u]++;
+                GT x; x.Exp(want[t][2], ks[t][3]);
+                if (!x.Equal(wantExp[t])) bad2[u]++;
+            }
+        });
+    for (auto &x : th2) x.join();
+    int total2 = 0;
+    for (int u = 0; u < T2; u++) total2 += bad2[u];
+    if (total2) { printf("FAIL: %d mismatches among 64 threads of single calls\n", total2); return 1; }
     printf("threads OK\n");
     return 0;
 }

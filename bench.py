@@ -22,7 +22,12 @@ Extra objects on the JSON line:
   cpu_baseline the C restatement (oracle/, "port") timed on all host cores this process may use, rank 0, N=1 only, bounded
                sample; cpu_baseline_1core the same on one thread; actual_fp_mul its instrumented Fp-mul counts.
   value_pcie_inclusive  the host-pointer entry gpbc_pair_batch on the same batch (upload + kernels + download).
-  secondary    G1/G2 scalar-mult rates, wire / hash-to-curve / fixed-base / GT.Exp rates, and `configs`: BASELINE configs
+  roofline.scalar_mul   the other half of the metric: G1 and G2 scalar-mults/s at the same batch, each with its kernel's time from
+               the same HIP-event bracket, the nominal (2 500 / 7 500 Fp-mul x 136 MAC) and executed-MAD fractions.
+  concurrent_calls      calls/s of T = 1, 8, 64 OS threads looping ONE-element host-pointer calls (the reference's call shape; native
+               harness tools/concurrent_calls.cpp over the C ABI, every result compared); a compact copy sits in cpu_baseline beside
+               the port's rates.
+  secondary    wire / hash-to-curve / fixed-base / GT.Exp rates, and `configs`: BASELINE configs
                2-4 at their stated sizes (aggregate verification of 2^20 signatures, BSW07 decrypt of 2^16 ciphertexts under
                both 256-attribute policies, AFP25 batch decryption of 2^18 identities), each timed and checked; with N > 1
                they shard over the ranks and run their all-gather through the library's own RCCL communicator.
@@ -122,6 +127,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="headline line only (scalar-mult rates, extras and config legs skipped)")
     ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE config 2-4 legs")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline (profiling runs)")
+    ap.add_argument("--no-scalar-mul", action="store_true", help="skip the G1/G2 scalar-mult half of the metric (roofline.scalar_mul)")
     ap.add_argument("--config-scale", type=int, default=1, help="divide the config-leg sizes by this (quick runs; 1 = BASELINE sizes)")
     args = ap.parse_args()
 
@@ -261,7 +267,7 @@ def main():
 
     value = world * B * args.steps / dt
     result = {
-        "metric": "BN254 pairings/s at batch 2^20 per GPU (+ G1/G2 scalar-mults/s in `secondary`)",
+        "metric": "BN254 pairings/s at batch 2^20 per GPU (+ G1/G2 scalar-mults/s at the same batch in roofline.scalar_mul)",
         "value": value, "unit": "pairings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "int64", "data": "synthetic",
@@ -333,26 +339,47 @@ def main():
                 "kernel times from HIP events on the launch stream around every launch of the timed steps",
     }
     sec = {}
-    # ---- secondary metric: scalar multiplications at the same batch
-    if not args.no_secondary:
+    # ---- the other half of the metric: G1 / G2 scalar multiplications at the same batch (bases P_i / Q_i, scalars k("s", i)), HBM
+    # resident, whole-job rate; the kernels' own time from the same HIP-event bracket as the pairing kernels
+    ks = None
+    if not args.no_scalar_mul:
         ks = torch.from_numpy(wl.bench_scalars("s", rank * B, B).copy()).to(dev).reshape(B, 32)
+        smul = {}
+        REPS = 2
         for name, fn, base, nominal in (("g1", bn254.g1_scalar_mul, P, FP_MUL_G1), ("g2", bn254.g2_scalar_mul, Q, FP_MUL_G2)):
             out = torch.empty_like(base)
             fn(base, ks, out=out)                       # untimed warm-up pass
             barrier()
+            _lib.check(lib.gpbc_profile_begin(stream))
             t1 = time.perf_counter()
-            for _ in range(2):
+            for _ in range(REPS):
                 fn(base, ks, out=out)
             barrier()
-            d = max_over_ranks((time.perf_counter() - t1) / 2)
-            sec[name + "_scalar_mults_per_s"] = world * B / d
-            sec[name + "_frac_of_valu_peak"] = nominal * MAC_PER_FP_MUL * B / d / 1e12 / PEAK_TMAC_PER_S
-            # the nominal count above is SURVEY's (2 500 / 7 500 Fp-mul x 136); what the kernel EXECUTES is counted by the interval
-            # harness (tools/bounds_check.cpp runs the device code on the host and counts its limb products): MADs per unit
+            d = max_over_ranks((time.perf_counter() - t1) / REPS)
+            _lib.check(lib.gpbc_profile_end(names, ms, cnt, 16, ctypes.byref(nk)))
+            kname = "k_%s_scalar_mul" % name
+            k_ms, k_launches = None, None
+            for i in range(nk.value):
+                if names.raw[32 * i:32 * i + 32].split(b"\0")[0].decode() == kname:
+                    k_ms, k_launches = ms[i] / REPS, cnt[i] / REPS
+            # the nominal count is SURVEY's (2 500 / 7 500 Fp-mul x 136); what the kernel EXECUTES is counted by the interval harness
+            # (tools/bounds_check.cpp runs the device code on the host and counts its limb products): MADs per unit
             ex = EXECUTED_MAD.get(name)
-            if ex:
-                sec[name + "_executed_mad_per_unit"] = ex
-                sec[name + "_executed_mad_frac_of_same_run_peak"] = ex * B / d / 1e12 / peak_now
+            e = {"per_s": world * B / d, "unit": "%s scalar-mults/s, whole job, 254-bit scalars, one base per scalar" % name.upper(), "ms_per_batch": 1e3 * d,
+                 "kernel": kname, "kernel_ms_per_batch": k_ms, "kernel_launches_per_batch": k_launches,
+                 "nominal_fp_mul": nominal, "frac": nominal * MAC_PER_FP_MUL * B / d / 1e12 / PEAK_TMAC_PER_S,
+                 "frac_same_run_peak": nominal * MAC_PER_FP_MUL * B / d / 1e12 / peak_now,
+                 "kernel_frac": (nominal * MAC_PER_FP_MUL * B / (k_ms * 1e-3) / 1e12 / PEAK_TMAC_PER_S) if k_ms else None,
+                 "simd_cycles_per_unit": (k_ms * 1e-3 * clock_hz * n_simd / B) if k_ms else None,
+                 "executed_mad_per_unit": ex, "executed_mad_frac_of_same_run_peak": (ex * B / d / 1e12 / peak_now) if ex else None,
+                 "valu_instr_per_wave_from_profiles": pmc.get("kernels", {}).get(kname, {}).get("valu_instr_per_wave")}
+            smul[name] = e
+            sec[name + "_scalar_mults_per_s"] = e["per_s"]
+            sec[name + "_frac_of_valu_peak"] = e["frac"]
+        result["roofline"]["scalar_mul"] = smul
+    if not args.no_secondary:
+        if ks is None:
+            ks = torch.from_numpy(wl.bench_scalars("s", rank * B, B).copy()).to(dev).reshape(B, 32)
 
         # The remaining lines (wire formats, hash to curve, fixed-base tables, GT.Exp) are per-GPU rates of independent
         # kernels: measured on the single-GPU run only, and never allowed to take the headline JSON line down with them.
@@ -598,6 +625,27 @@ def main():
             result["call_latency_ms"] = {"error": repr(exc)}
         base, one, counts = cpu_baseline(P, Q, gt, B)
         result["cpu_baseline"], result["cpu_baseline_1core"], result["actual_fp_mul"] = base, one, counts
+        # ---- the reference's call shape under concurrency: T OS threads looping one-element calls through the C ABI (native harness:
+        # Python threads would measure the interpreter lock); a child process on the same device, this one idle meanwhile
+        try:
+            import subprocess
+            exe = os.path.join(ROOT, "gopairingbasedcryptography_amd", "gpbc_concurrent_calls")
+            cc = subprocess.run([exe, "--device", str(local_rank), "--seconds", "1", "--threads", "1,8,64"], capture_output=True, text=True, timeout=300)
+            if cc.returncode != 0:
+                raise RuntimeError("gpbc_concurrent_calls exit %d: %s" % (cc.returncode, (cc.stderr or cc.stdout)[-400:]))
+            calls = json.loads(cc.stdout.strip().splitlines()[-1])
+            if calls.get("mismatches"):
+                raise SystemExit("PARITY FAILURE: concurrent single calls returned wrong bytes")
+            result["concurrent_calls"] = calls
+            base["concurrent_calls"] = {
+                "what": "GPU: calls/s of T OS threads looping one-element gpbc_pair_batch / gpbc_pairing_check (2 pairs) / gpbc_g1_scalar_mul_batch "
+                        "(tools/concurrent_calls.cpp, results compared); port: the C restatement's pairings/s on 1 and on %d threads" % base["cores"],
+                "gpu_calls_per_s": {op: {t: v["calls_per_s"] for t, v in calls[op].items()} for op in ("pair_batch_1", "pairing_check_2_pairs", "g1_scalar_mul_1")},
+                "port_pairings_per_s": {"1": one["value"], str(base["cores"]): base["value"]}}
+        except SystemExit:
+            raise
+        except Exception as exc:                          # noqa: BLE001
+            result["concurrent_calls"] = {"error": repr(exc)}
     if rank == 0:
         print(json.dumps(result))
     if use_dist:

@@ -12,7 +12,7 @@ EXPORTS = [
     "gpbc_set_host_sharding", "gpbc_shutdown", "gpbc_last_error", "gpbc_device_count", "gpbc_abi_version",
     "gpbc_comm_init_all", "gpbc_comm_get_unique_id", "gpbc_comm_init_rank", "gpbc_comm_ranks", "gpbc_comm_rank", "gpbc_comm_destroy",
     "gpbc_allgather_dev", "gpbc_allgather_all_dev",
-    "gpbc_g1_scalar_mul_sum", "gpbc_g2_scalar_mul_sum", "gpbc_g1_scalar_mul_sum_dev", "gpbc_g2_scalar_mul_sum_dev",
+    "gpbc_g1_scalar_mul_sum", "gpbc_g2_scalar_mul_sum", "gpbc_g1_scalar_mul_sum_dev", "gpbc_g2_scalar_mul_sum_dev", "gpbc_msm_stats",
     "gpbc_pair_batch", "gpbc_pair_batch_dev", "gpbc_multi_pair", "gpbc_multi_pair_workspace_bytes",
     "gpbc_multi_pair_dev", "gpbc_check_segments_dev", "gpbc_multi_pair_hostseg_dev", "gpbc_set_multi_pair_chunk", "gpbc_multi_pair_fixed_q", "gpbc_multi_pair_fixed_q_dev", "gpbc_pairing_check", "gpbc_miller_loop_dev", "gpbc_final_exp_dev",
     "gpbc_miller_loop", "gpbc_final_exp",

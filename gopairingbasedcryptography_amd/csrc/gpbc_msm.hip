@@ -13,6 +13,10 @@
 //   k_msm_rows_sum   fan-in-8 sums of the group rows of a window, level by level (serial chains of 8 additions, not 64:
 //                    these last steps have few lanes and are latency-bound)
 //   k_msm_finish     one lane: Horner over the windows, affine result in gnark's layout
+// The PARTIAL top window (c = 12: W = 22 and window 21 holds bits 252..255 only; uniform scalars below r put a third of the terms
+// into each of its digits 1 and 2): its 2^c keys are  (term index mod S) * D + digit  with D = 2^(256 - c (W - 1)) digit values and
+// S = 2^c / D sub-buckets per digit, so that its terms spread over the whole key range like any other window's; step 3 then weighs
+// a key by its low bits (the digit) instead of the key itself.  Nothing else changes: the tree sum of the window adds the sub-buckets.
 // All scratch is one stream-ordered allocation; the call is asynchronous on `stream`.
 #include "gpbc_common.hpp"
 #include "msm29.hip.hpp"
@@ -36,9 +40,11 @@ __global__ void __launch_bounds__(BLOCK) k_msm_keys(const uint8_t *__restrict__ 
     if (base_is_inf<F>(bases + i * PT)) return;
     uint32_t k[8];
     load_scalar(k, scalars + i * GPBC_SCALAR_BYTES);
+    const int top_bits = 256 - c * (W - 1);                  // digit bits of the last window (= c when c divides 256)
     for (int w = 0; w < W; w++) {
-        const uint32_t d = msm_digit(k, w, c);
+        uint32_t d = msm_digit(k, w, c);
         if (!d) continue;
+        if (w == W - 1 && top_bits < c) d |= ((uint32_t)i & ((1u << (c - top_bits)) - 1u)) << top_bits;     // sub-bucket (i mod S) above the digit
         const uint32_t key = ((uint32_t)w << c) | d;
         const uint32_t pos = atomicAdd(&counts[key], 1u);
         if (SCATTER) idx[offsets[key] + pos] = (uint32_t)i;
@@ -46,14 +52,15 @@ __global__ void __launch_bounds__(BLOCK) k_msm_keys(const uint8_t *__restrict__ 
 }
 
 // the longest bucket: one lane adds a whole bucket serially (k_msm_buckets), so its length is the depth of the bucket stage
-__global__ void __launch_bounds__(SCAN_BLOCK) k_msm_max_count(const uint32_t *__restrict__ counts, size_t M, uint32_t *__restrict__ out) {
+// out[w] = the longest bucket of window w (a block of 256 keys lies inside one window: 2^c is a multiple of 256)
+__global__ void __launch_bounds__(SCAN_BLOCK) k_msm_max_count(const uint32_t *__restrict__ counts, size_t M, int c, uint32_t *__restrict__ out) {
     __shared__ uint32_t sh;
     if (threadIdx.x == 0) sh = 0;
     __syncthreads();
     const size_t key = (size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
     if (key < M && counts[key]) atomicMax(&sh, counts[key]);
     __syncthreads();
-    if (threadIdx.x == 0 && sh) atomicMax(out, sh);
+    if (threadIdx.x == 0 && sh) atomicMax(&out[((size_t)blockIdx.x * SCAN_BLOCK) >> c], sh);
 }
 
 // exclusive scan of m counters: per-tile scan + tile totals, scan of the totals (one block), add-back
@@ -162,13 +169,18 @@ k_msm_buckets(const int32_t *__restrict__ base_rows, const uint32_t *__restrict_
     jac_row_store(rows + key * JacRow<F>::DWORDS, acc);
 }
 template <class F> __global__ void __launch_bounds__(BLOCK, sizeof(F) == sizeof(Fe) ? GPBC_WAVES_G1 : GPBC_WAVES_PER_SIMD)
-k_msm_groups(const int32_t *__restrict__ buckets, int c, size_t n_groups_total, int32_t *__restrict__ out) {
+k_msm_groups(const int32_t *__restrict__ buckets, int c, int W, size_t n_groups_total, int32_t *__restrict__ out) {
     size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (t >= n_groups_total) return;
     const size_t groups_per_window = ((size_t)1 << c) / MSM_GROUP;
     const size_t w = t / groups_per_window, g = t % groups_per_window;
-    const uint32_t lo = (uint32_t)(g * MSM_GROUP), hi = lo + MSM_GROUP - 1;
-    const int32_t *win = buckets + (w << c) * JacRow<F>::DWORDS;
+    const int top_bits = 256 - c * (W - 1);
+    // keys [first, first + 8) of the window; a key's weight is the key itself, or — in a partial top window — its low top_bits bits
+    // (the digit; the bits above number the sub-bucket): weights lo..hi sit at keys key0 + lo .. key0 + hi
+    const uint32_t first = (uint32_t)(g * MSM_GROUP);
+    const uint32_t dmask = ((int)w == W - 1 && top_bits < c) ? (1u << top_bits) - 1u : ~0u;
+    const uint32_t lo = first & dmask, hi = lo + MSM_GROUP - 1, key0 = first - lo;
+    const int32_t *win = buckets + ((w << c) + key0) * JacRow<F>::DWORDS;
     JacP<F> r;
     msm_group_reduce(r, lo ? lo : 1u, hi, [&](uint32_t d) { JacP<F> b; jac_row_load(b, win + (size_t)d * JacRow<F>::DWORDS); return b; });
     jac_row_store(out + t * JacRow<F>::DWORDS, r);
@@ -209,11 +221,13 @@ template <class F> __global__ void __launch_bounds__(BLOCK) k_msm_finish(const i
 }
 
 constexpr size_t MSM_FAN = 8;
+static std::atomic<uint64_t> g_msm_bucket_runs{0}, g_msm_skewed{0};       // which way msm_run went (gpbc_msm_stats: tests assert the path)
 struct MsmPlan { int c, W; size_t M, n_groups, n_size_blocks, bytes; size_t off_counts, off_offsets, off_tiles, off_total, off_idx, off_buckets, off_groups, off_tmp, off_bases, off_hist, off_hist_scanned, off_perm; };
 static MsmPlan msm_plan(bool g2, size_t n) {
     MsmPlan p;
     p.c = n >= ((size_t)1 << 17) ? 16 : 12;
     p.W = (256 + p.c - 1) / p.c;
+    static_assert(256 - 12 * 21 == 4 && 256 % 16 == 0, "c = 12 leaves a 4-bit top window (16 digit values >= MSM_GROUP: a group of step 3 stays inside one sub-bucket row), c = 16 none");
     p.M = (size_t)p.W << p.c;
     p.n_groups = p.M / MSM_GROUP;
     const size_t row = (g2 ? JacRow<F2>::DWORDS : JacRow<Fe>::DWORDS) * sizeof(int32_t);
@@ -263,10 +277,18 @@ template <class F> static int msm_run(const uint8_t *d_bases, const uint8_t *d_s
     if (rc == GPBC_OK) {
         uint8_t *pin = nullptr;
         rc = pinned_staging(st, 4096, &pin);
-        if (rc == GPBC_OK && hipMemsetAsync(total, 0, 4, st) != hipSuccess) rc = fail(GPBC_ERR_HIP, "hipMemsetAsync failed");
-        if (rc == GPBC_OK) { k_msm_max_count<<<(unsigned)((p.M + SCAN_BLOCK - 1) / SCAN_BLOCK), SCAN_BLOCK, 0, st>>>(counts, p.M, total); step("k_msm_max_count"); }
-        if (rc == GPBC_OK && (hipMemcpyAsync(pin, total, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) rc = fail(GPBC_ERR_HIP, "read-back of the longest bucket failed");
-        if (rc == GPBC_OK && *(const uint32_t *)pin > MSM_MAX_BUCKET_BASE + 8 * (uint32_t)(n >> p.c)) return MSM_SKEWED;
+        // one maximum per window (W <= 22 words in the 256-byte `total` slot), each judged against the mean of a full window; the
+        // partial top window is spread over its sub-buckets (k_msm_keys), so the same bound holds for it
+        static_assert(sizeof(uint32_t) * 32 <= 256, "per-window maxima live in the `total` slot");
+        if (rc == GPBC_OK && hipMemsetAsync(total, 0, 4 * (size_t)p.W, st) != hipSuccess) rc = fail(GPBC_ERR_HIP, "hipMemsetAsync failed");
+        if (rc == GPBC_OK) { k_msm_max_count<<<(unsigned)((p.M + SCAN_BLOCK - 1) / SCAN_BLOCK), SCAN_BLOCK, 0, st>>>(counts, p.M, p.c, total); step("k_msm_max_count"); }
+        if (rc == GPBC_OK && (hipMemcpyAsync(pin, total, 4 * (size_t)p.W, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) rc = fail(GPBC_ERR_HIP, "read-back of the longest buckets failed");
+        if (rc == GPBC_OK) {
+            uint32_t longest = 0;
+            for (int w = 0; w < p.W; w++) if (((const uint32_t *)pin)[w] > longest) longest = ((const uint32_t *)pin)[w];
+            if (longest > MSM_MAX_BUCKET_BASE + 8 * (uint32_t)(n >> p.c)) { g_msm_skewed.fetch_add(1); return MSM_SKEWED; }
+            g_msm_bucket_runs.fetch_add(1);
+        }
     }
     if (rc == GPBC_OK) { k_scan_tiles<<<(unsigned)n_tiles, SCAN_BLOCK, 0, st>>>(counts, offsets, tiles, p.M); step("k_scan_tiles"); }
     if (rc == GPBC_OK) { k_scan_tops<<<1, SCAN_BLOCK, 0, st>>>(tiles, n_tiles, total); step("k_scan_tops"); }
@@ -282,7 +304,7 @@ template <class F> static int msm_run(const uint8_t *d_bases, const uint8_t *d_s
     if (rc == GPBC_OK) { k_scan_add<<<(unsigned)hist_tiles, SCAN_BLOCK, 0, st>>>(hist_scanned, tiles, hist_len, total); step("k_scan_add"); }
     if (rc == GPBC_OK) { k_size_scatter<<<(unsigned)p.n_size_blocks, SCAN_BLOCK, 0, st>>>(offsets, p.M, p.c, hist_scanned, p.n_size_blocks, perm); step("k_size_scatter"); }
     if (rc == GPBC_OK) { k_msm_buckets<F><<<grid_for(p.M), BLOCK, 0, st>>>(base_rows, offsets, idx, perm, p.c, p.M, buckets); step(G2 ? "k_msm_buckets_g2" : "k_msm_buckets_g1"); }
-    if (rc == GPBC_OK) { k_msm_groups<F><<<grid_for(p.n_groups), BLOCK, 0, st>>>(buckets, p.c, p.n_groups, groups); step(G2 ? "k_msm_groups_g2" : "k_msm_groups_g1"); }
+    if (rc == GPBC_OK) { k_msm_groups<F><<<grid_for(p.n_groups), BLOCK, 0, st>>>(buckets, p.c, p.W, p.n_groups, groups); step(G2 ? "k_msm_groups_g2" : "k_msm_groups_g1"); }
     // tree over the groups of every window: rows are window-major, so segments of `fan` consecutive rows never cross a window
     int32_t *src = groups, *dst = tmp;
     for (size_t per_window = gpw; rc == GPBC_OK && per_window > 1;) {
@@ -302,4 +324,9 @@ int msm_dev(bool g2, const void *d_bases, const void *d_scalars, size_t n, void 
     TRY(bind_device());
     return g2 ? msm_run<F2>((const uint8_t *)d_bases, (const uint8_t *)d_scalars, n, (uint8_t *)d_out, st)
               : msm_run<Fe>((const uint8_t *)d_bases, (const uint8_t *)d_scalars, n, (uint8_t *)d_out, st);
+}
+extern "C" int gpbc_msm_stats(uint64_t *bucket_runs_out, uint64_t *skewed_fallbacks_out) {
+    if (!bucket_runs_out || !skewed_fallbacks_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
+    *bucket_runs_out = g_msm_bucket_runs.load(); *skewed_fallbacks_out = g_msm_skewed.load();
+    return GPBC_OK;
 }

@@ -205,6 +205,10 @@ int gpbc_g1_scalar_mul_sum(const void *bases, const void *scalars, size_t n, voi
 int gpbc_g2_scalar_mul_sum(const void *bases, const void *scalars, size_t n, void *out);
 int gpbc_g1_scalar_mul_sum_dev(const void *d_bases, const void *d_scalars, size_t n, void *d_out, void *stream);
 int gpbc_g2_scalar_mul_sum_dev(const void *d_bases, const void *d_scalars, size_t n, void *d_out, void *stream);
+/* Diagnostics: from 16 384 terms on the sums above take the bucket (Pippenger) method unless the digit histogram shows a bucket far
+ * longer than the mean (all scalars equal, small integers ...), in which case the terms are multiplied one by one.  Process-wide
+ * counts of the two outcomes since the library was loaded (tests assert which path a workload took). */
+int gpbc_msm_stats(uint64_t *bucket_runs_out, uint64_t *skewed_fallbacks_out);
 
 /* ---- GT arithmetic -----------------------------------------------------------------------------
  * (*GT).Exp(x, k) for k >= 0 (access/tree/access_tree_node.go:123,156; bibe/afp25_bibe/afp25_bibe.go:258-259);

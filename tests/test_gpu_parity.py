@@ -565,13 +565,7 @@ def test_one_process_drives_every_device(eng, tmp_path):
     assert out.returncode == 0 and "multi-device OK" in out.stdout, out.stdout + out.stderr
 
 
-def test_collective_paths_with_two_ranks_on_a_test_double(eng, tmp_path):
-    """The N > 1 collective code of the library — ncclCommInitAll over two slots, the grouped ncclAllGather of
-    gpbc_allgather_all_dev (rank order, offsets), the per-rank ncclAllGather inside gpbc_g1/g2_scalar_mul_sum_dev, a 10 000-signature
-    aggregate verification with a forged-signature reject on the gathered sums — executed with TWO ranks on the one GPU of this box:
-    real RCCL refuses the device list {0, 0}, so tests/stub_rccl/rccl_stub.cpp (a ~150-line librccl.so.1 that rendezvouses the
-    ranks on the host and copies device to device) stands in for it, found through LD_LIBRARY_PATH by the library's dlopen.  Test
-    infrastructure only: the product keeps real RCCL, and multi-GPU RATES remain unmeasured on hardware (SURVEY §8e, DESIGN §6)."""
+def _multi_device_on_the_test_double(tmp_path, slots):
     import subprocess
     from conftest import ROOT
     import os
@@ -584,11 +578,33 @@ def test_collective_paths_with_two_ranks_on_a_test_double(eng, tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-pthread", "-w", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROOT, "include"),
                            "-I/opt/rocm/include", os.path.join(ROOT, "tests", "cpp", "test_multi_device.cpp"),
                            "-L" + pkg, "-lgpbc_bn254", "-Wl,-rpath," + pkg, "-L/opt/rocm/lib", "-lamdhip64", "-o", exe])
-    env = dict(os.environ, GPBC_TEST_STUB_RCCL="1", LD_LIBRARY_PATH=stub_dir + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
-    out = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=env)
+    env = dict(os.environ, GPBC_TEST_STUB_RCCL="1", GPBC_TEST_SLOTS=str(slots), LD_LIBRARY_PATH=stub_dir + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=1100, env=env)
     assert out.returncode == 0 and "multi-device OK" in out.stdout, out.stdout + out.stderr
-    assert "RCCL all-gather over 2 rank(s) inside the library (rccl TEST DOUBLE" in out.stdout, out.stdout
-    assert "scalar_mul_sum_dev on 2 rank(s)" in out.stdout and "BLS aggregate verify over 2 rank(s)" in out.stdout, out.stdout
+    assert "%d bound slot(s)" % slots in out.stdout, out.stdout
+    assert "RCCL all-gather over %d rank(s) inside the library (rccl TEST DOUBLE" % slots in out.stdout, out.stdout
+    assert "scalar_mul_sum_dev on %d rank(s)" % slots in out.stdout and "BLS aggregate verify over %d rank(s)" % slots in out.stdout, out.stdout
+
+
+def test_collective_paths_with_eight_ranks_on_a_test_double(eng, tmp_path):
+    """The rank arithmetic of BASELINE's 8-GPU node, rehearsed in ONE process on this one GPU: tests/cpp/test_multi_device.cpp with
+    the device listed eight times (GPBC_TEST_SLOTS=8) over tests/stub_rccl — host entries sharded over 8 slots with ragged shares
+    (34 002 units: 4 251 and 4 250 per slot), one host thread per slot on *_dev entries, ncclCommInitAll over 8 ranks, rank order and
+    offsets of the gathered GT rows on every rank (config 5's shape: n/G x 384 B), scalar_mul_sum_dev with the 64 / 128-byte
+    partial sums all-gathered (config 3's shape: 192 B per rank) on every rank, aggregate verification accept / reject.  One process
+    because the pool allows six GPU processes at a time; the multi-PROCESS form runs with four ranks below.  Test infrastructure
+    only: real RCCL with more than one rank has never run here and multi-GPU rates remain UNMEASURED ON HARDWARE."""
+    _multi_device_on_the_test_double(tmp_path, 8)
+
+
+def test_collective_paths_with_two_ranks_on_a_test_double(eng, tmp_path):
+    """The N > 1 collective code of the library — ncclCommInitAll over two slots, the grouped ncclAllGather of
+    gpbc_allgather_all_dev (rank order, offsets), the per-rank ncclAllGather inside gpbc_g1/g2_scalar_mul_sum_dev, a 10 000-signature
+    aggregate verification with a forged-signature reject on the gathered sums — executed with TWO ranks on the one GPU of this box:
+    real RCCL refuses the device list {0, 0}, so tests/stub_rccl/rccl_stub.cpp (a ~150-line librccl.so.1 that rendezvouses the
+    ranks on the host and copies device to device) stands in for it, found through LD_LIBRARY_PATH by the library's dlopen.  Test
+    infrastructure only: the product keeps real RCCL, and multi-GPU RATES remain unmeasured on hardware (SURVEY §8e, DESIGN §6)."""
+    _multi_device_on_the_test_double(tmp_path, 2)
 
 
 def test_two_process_ranks_over_the_test_double(eng, tmp_path):
@@ -606,18 +622,24 @@ def test_two_process_ranks_over_the_test_double(eng, tmp_path):
     subprocess.check_call(["g++", "-O1", "-shared", "-fPIC", "-pthread", "-w", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
                            os.path.join(ROOT, "tests", "stub_rccl", "rccl_stub.cpp"), "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-o", stub])
     env = dict(os.environ, GPBC_BENCH_REHEARSAL="stub", GPBC_RCCL_LIBRARY=stub, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29531",
-                          os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "16384", "--config-scale", "64", "--no-cpu"],
-                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
-    line = json.loads(out.stdout.strip().splitlines()[-1])
-    assert line["n_gpus"] == 2 and "TEST DOUBLE" in line["config"]["rehearsal"]
-    legs = line["secondary"]["configs"]
-    assert legs.get("comm_error") is None, legs
-    for name in ("aggregate_verify_2^20", "bsw07_256of256_2^16", "afp25_2^18"):
-        assert "error" not in legs[name], (name, legs[name])
-    assert legs["aggregate_verify_2^20"]["accepts"] and legs["aggregate_verify_2^20"]["rejects_forged"]
-    assert legs["afp25_2^18"]["all_messages_recovered"] and legs["afp25_2^18"]["collective"]
+    # two ranks at even sizes, then FOUR ranks with ragged ones (--batch 16387; --config-scale 61: 17 189 signatures = 4 298 + 3 x 4 297,
+    # 1 074 ciphertexts = 269 + 269 + 268 + 268).  Four, not eight, rank processes: the pool allows six GPU processes at a time and the
+    # test runner is one of them; the 8-rank arithmetic runs in one process above.
+    for ranks, batch, scale, port in ((2, "16384", "64", "29531"), (4, "16387", "61", "29533")):
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1", "--master-port", port,
+                              os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "1", "--warmup", "1", "--batch", batch, "--config-scale", scale, "--no-cpu"],
+                             capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+        line = json.loads(out.stdout.strip().splitlines()[-1])
+        assert line["n_gpus"] == ranks and "TEST DOUBLE" in line["config"]["rehearsal"]
+        legs = line["secondary"]["configs"]
+        assert legs.get("comm_error") is None, legs
+        for name in ("aggregate_verify_2^20", "bsw07_256of256_2^16", "afp25_2^18"):
+            assert "error" not in legs[name], (ranks, name, legs[name])
+        assert legs["aggregate_verify_2^20"]["accepts"] and legs["aggregate_verify_2^20"]["rejects_forged"]
+        assert legs["bsw07_256of256_2^16"]["all_messages_recovered"]
+        assert legs["afp25_2^18"]["all_messages_recovered"] and legs["afp25_2^18"]["collective"]
+        assert ("%d ranks" % ranks) in legs["aggregate_verify_2^20"]["collective"]
 
 
 def test_large_batch_chunks_and_properties(eng, oracle):
@@ -1008,12 +1030,24 @@ def test_bucket_msm_against_scalar_multiplications(eng, oracle):
     """gpbc_g1/g2_scalar_mul_sum from 16 384 terms on runs the bucket (Pippenger) method of csrc/gpbc_msm.hip: both window sizes
     (12-bit below 2^17 terms, 16-bit from there), full-width scalars (values >= r included), zero scalars, points at infinity
     and repeated bases, against the sum of the engine's independent scalar multiplications and, on the small case, the oracle."""
+    import ctypes
     import torch
+    from gopairingbasedcryptography_amd import _lib
+    def paths():                     # (bucket runs, skew fallbacks) so far — which way the sums went
+        a, b = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        _lib.check(_lib.load().gpbc_msm_stats(ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
     g1, g2 = eng.generators()
     rng = np.random.default_rng(1234)
-    for n in (20001, 140003):
+    # full-width scalars at both window sizes; 128-bit scalars (the rho of BLS aggregate verification) and scalars below r (what every
+    # reference call site passes: their top window holds digits 0..3 only) in the 12-bit range
+    for n, kind in ((20001, "full"), (140003, "full"), (20001, "128bit"), (20001, "below_r")):
         K = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
-        K[0] = 0; K[1] = 255; K[2, 1:] = 0; K[5, 16:] = 0
+        if kind == "128bit":
+            K[:, 16:] = 0
+        if kind == "below_r":
+            K[:, 31] &= 0x1F                                          # < 2^253 < r
+        K[0] = 0; K[1] = 255 if kind == "full" else K[1]; K[2, 1:] = 0; K[5, 16:] = 0
         kb = rng.integers(0, 256, size=(n, 32), dtype=np.uint8); kb[:, 31] &= 0x1F
         dK, dkb = torch.from_numpy(K).cuda(), torch.from_numpy(kb).cuda()
         for gen, mul, summ, msm, w in ((g1, eng.g1_scalar_mul, eng.g1_sum, eng.g1_scalar_mul_sum, 64), (g2, eng.g2_scalar_mul, eng.g2_sum, eng.g2_scalar_mul_sum, 128)):
@@ -1021,9 +1055,14 @@ def test_bucket_msm_against_scalar_multiplications(eng, oracle):
             B[3] = 0                                                  # infinity
             B[7] = B[6]; dK[7] = dK[6]                               # same base and scalar twice
             want = summ(mul(B, dK)).cpu().numpy()
+            before = paths()
             got = msm(B, dK).cpu().numpy()
-            assert (got == want).all(), (n, w)
-            assert (msm(B.cpu().numpy(), dK.cpu().numpy()) == want).all(), (n, w, "host entry")
+            assert (got == want).all(), (n, kind, w)
+            after = paths()
+            assert after[0] == before[0] + 1 and after[1] == before[1], ("random scalars must take the bucket path, not the fallback", n, kind, w, before, after)
+            assert (msm(B.cpu().numpy(), dK.cpu().numpy()) == want).all(), (n, kind, w, "host entry")
+            if kind != "full":
+                continue
             if n < 50000:
                 o_want = np.asarray(oracle.g1_sum(oracle.g1_scalar_mul(B.cpu().numpy(), dK.cpu().numpy(), threads=16)) if w == 64 else
                                     oracle.g2_sum(oracle.g2_scalar_mul(B.cpu().numpy(), dK.cpu().numpy(), threads=16))).reshape(-1)
@@ -1036,9 +1075,11 @@ def test_bucket_msm_against_scalar_multiplications(eng, oracle):
                              ("one", np.pad(np.ones((n, 1), np.uint8), ((0, 0), (0, 31))))):
                 dKs = torch.from_numpy(np.ascontiguousarray(Ks)).cuda()
                 want_s = summ(mul(B, dKs)).cpu().numpy()
+                before = paths()
                 torch.cuda.synchronize(); t0 = time.perf_counter()
                 got_s = msm(B, dKs).cpu().numpy()
                 dt = time.perf_counter() - t0
+                assert paths() == (before[0], before[1] + 1), ("skewed scalars must take the per-term path", n, w, name)
                 assert (got_s == want_s).all(), (n, w, name)
                 assert dt < 1.0, (n, w, name, dt)
                 assert (msm(B.cpu().numpy(), Ks) == want_s).all(), (n, w, name, "host entry")

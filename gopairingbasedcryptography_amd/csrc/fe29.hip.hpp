@@ -370,80 +370,6 @@ GPBC_INLINE void fe_sqrdiff_mul_dual(Fe &r0, Fe &r1, const Fe &a0, const Fe &a1)
 #endif
 }
 
-// The same products for a LONE wave (the latency form, wide29.hip.hpp: one pairing per wavefront, one or two waves on a SIMD).  A lone
-// wave is bound by the LATENCY of its dependent chains, not by issue: one dependent v_mad_i64_i32 chain advances every ~14.5 cycles,
-// four independent ones every ~4.5 each (profiles/r03_microbench_valu2.txt).  The column-wise form above is one or two long chains; this
-// one is row-wise (operand scanning): all 2 NL - 1 product columns live at once, the nine MADs of a row go to nine DIFFERENT columns, and
-// the reduction adds each Montgomery digit's row the same way — nine or more independent chains at every point, the only serial thread
-// being the digits themselves (add carry, multiply by -1/p, mask, one MAD: nine times).  Same column sums, same digits, same output limbs
-// as fe_mul_core — integer addition is associative — so the two forms are interchangeable bit for bit; the throughput kernels (two waves
-// per SIMD, issue-bound) keep the column-wise form, which needs 2 instead of 2 NL + 1 accumulators.
-// Bounds: partial sums are taken in another order, so the harness asks for the sum of the term MAGNITUDES of a column to fit (the
-// column-wise form gets away with the signed interval of the finished sum).
-template <bool TWO, bool DUAL>
-GPBC_INLINE void fe_mul_rows(Fe &r0, Fe &r1, const Fe &a0, const Fe &b0, const Fe &c0, const Fe &d0, const Fe &a1, const Fe &b1, const Fe &c1, const Fe &d1) {
-#ifdef GPBC_BOUNDS
-    auto magnitudes = [](const Fe &a, const Fe &b, const Fe &c, const Fe &d) {
-        for (int k = 0; k < 2 * NL - 1; k++) {
-            double s = 0;
-            for (int i = 0; i < NL; i++) {
-                int j = k - i;
-                if (j < 0 || j >= NL) continue;
-                s += limb_mag(a, i) * limb_mag(b, j);
-                if (TWO) s += limb_mag(c, i) * limb_mag(d, j);
-            }
-            check_columns(-s, s, "fe_mul_rows column (sum of magnitudes)");
-        }
-    };
-    magnitudes(a0, b0, c0, d0);
-    r0 = fe_mul_core<TWO>(a0, b0, c0, d0);
-    if (DUAL) { magnitudes(a1, b1, c1, d1); r1 = fe_mul_core<TWO>(a1, b1, c1, d1); }
-#else
-    int64_t x[2 * NL - 1], y[2 * NL - 1];
-#pragma unroll
-    for (int k = 0; k < 2 * NL - 1; k++) { x[k] = 0; y[k] = 0; }
-#pragma unroll
-    for (int i = 0; i < NL; i++) {
-#pragma unroll
-        for (int j = 0; j < NL; j++) {
-            x[i + j] += (int64_t)a0.v[i] * (int64_t)b0.v[j];
-            if (DUAL) y[i + j] += (int64_t)a1.v[i] * (int64_t)b1.v[j];
-        }
-        if (TWO) {
-#pragma unroll
-            for (int j = 0; j < NL; j++) {
-                x[i + j] += (int64_t)c0.v[i] * (int64_t)d0.v[j];
-                if (DUAL) y[i + j] += (int64_t)c1.v[i] * (int64_t)d1.v[j];
-            }
-        }
-    }
-    int64_t cx = 0, cy = 0;
-#pragma unroll
-    for (int k = 0; k < NL; k++) {
-        int64_t tx = x[k] + cx, ty = y[k] + cy;
-        const int32_t mx = (int32_t)(((uint32_t)tx * (uint32_t)F29_PINV) & (uint32_t)LMASK);
-        const int32_t my = DUAL ? (int32_t)(((uint32_t)ty * (uint32_t)F29_PINV) & (uint32_t)LMASK) : 0;
-        tx += (int64_t)mx * (int64_t)f29_p(0);
-        if (DUAL) ty += (int64_t)my * (int64_t)f29_p(0);
-        cx = tx >> LB; cy = ty >> LB;
-#pragma unroll
-        for (int j = 1; j < NL; j++) {
-            x[k + j] += (int64_t)mx * (int64_t)f29_p(j);
-            if (DUAL) y[k + j] += (int64_t)my * (int64_t)f29_p(j);
-        }
-    }
-#pragma unroll
-    for (int k = NL; k < 2 * NL - 1; k++) {
-        const int64_t tx = x[k] + cx, ty = y[k] + cy;
-        r0.v[k - NL] = (int32_t)(tx & LMASK);
-        if (DUAL) r1.v[k - NL] = (int32_t)(ty & LMASK);
-        cx = tx >> LB; cy = ty >> LB;
-    }
-    r0.v[NL - 1] = (int32_t)cx;
-    if (DUAL) r1.v[NL - 1] = (int32_t)cy;
-#endif
-}
-
 #define GPBC_ARGS9(x) int32_t x##0, int32_t x##1, int32_t x##2, int32_t x##3, int32_t x##4, int32_t x##5, int32_t x##6, int32_t x##7, int32_t x##8
 #define GPBC_PASS9(x) x.v[0], x.v[1], x.v[2], x.v[3], x.v[4], x.v[5], x.v[6], x.v[7], x.v[8]
 #define GPBC_PACK9(x) Fe{{x##0, x##1, x##2, x##3, x##4, x##5, x##6, x##7, x##8}}

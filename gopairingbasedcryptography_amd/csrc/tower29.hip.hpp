@@ -112,43 +112,6 @@ GPBC_INLINE Fe fe_mul2_l(const Fe &a, const Fe &b, const Fe &c, const Fe &d) {
     g_f2_arg_slot4[lane] = d.v[4];
     return fe_mul2_lds_leaf(GPBC_PASS9(a), GPBC_PASS9(b), GPBC_PASS9(c), d.v[0], d.v[1], d.v[2], d.v[3]);
 }
-// The leaves of the LATENCY form (wide29.hip.hpp), row-wise (fe_mul_rows: many independent MAD chains for a lone wave): one half of an
-// F2 product, one Fp product, one whole F2 product.  Same bits as the leaves above.
-__device__ __noinline__ Fe fe_mul2_lone_leaf(GPBC_ARGS9(a), GPBC_ARGS9(b), GPBC_ARGS9(c), int32_t d0, int32_t d1, int32_t d2, int32_t d3) {
-    const unsigned lane = f2_arg_lane();
-    const i32x4 t = g_f2_arg_slot[lane];
-    const int32_t d4 = g_f2_arg_slot4[lane], d5 = t.x, d6 = t.y, d7 = t.z, d8 = t.w;
-    Fe a = GPBC_PACK9(a), b = GPBC_PACK9(b), c = GPBC_PACK9(c), d = GPBC_PACK9(d), r, unused;
-    fe_mul_rows<true, false>(r, unused, a, b, c, d, a, b, c, d);
-    return r;
-}
-GPBC_INLINE Fe fe_mul2_w(const Fe &a, const Fe &b, const Fe &c, const Fe &d) {
-    const unsigned lane = f2_arg_lane();
-    g_f2_arg_slot[lane] = i32x4{d.v[5], d.v[6], d.v[7], d.v[8]};
-    g_f2_arg_slot4[lane] = d.v[4];
-    return fe_mul2_lone_leaf(GPBC_PASS9(a), GPBC_PASS9(b), GPBC_PASS9(c), d.v[0], d.v[1], d.v[2], d.v[3]);
-}
-__device__ __noinline__ Fe fe_mul_lone_leaf(GPBC_ARGS9(a), GPBC_ARGS9(b)) {
-    Fe a = GPBC_PACK9(a), b = GPBC_PACK9(b), r, unused;
-    fe_mul_rows<false, false>(r, unused, a, b, a, b, a, b, a, b);
-    return r;
-}
-GPBC_INLINE Fe fe_mul_w(const Fe &a, const Fe &b) { return fe_mul_lone_leaf(GPBC_PASS9(a), GPBC_PASS9(b)); }
-__device__ __noinline__ i32x18 f2_mul_lone_leaf(GPBC_ARGS9(a), GPBC_ARGS9(b), GPBC_ARGS9(c), int32_t d0, int32_t d1, int32_t d2, int32_t d3) {
-    const unsigned lane = f2_arg_lane();
-    const i32x4 t = g_f2_arg_slot[lane];
-    const int32_t d4 = g_f2_arg_slot4[lane], d5 = t.x, d6 = t.y, d7 = t.z, d8 = t.w;
-    const F2 x = GPBC_PACK_F2(a, b), y = GPBC_PACK_F2(c, d);
-    F2 r;
-    fe_mul_rows<true, true>(r.a0, r.a1, x.a0, y.a0, fe_neg(x.a1), y.a1, x.a0, y.a1, x.a1, y.a0);
-    return f2_to_vec(r);
-}
-GPBC_INLINE F2 f2_mul_w(const F2 &x, const F2 &y) {
-    const unsigned lane = f2_arg_lane();
-    g_f2_arg_slot[lane] = i32x4{y.a1.v[5], y.a1.v[6], y.a1.v[7], y.a1.v[8]};
-    g_f2_arg_slot4[lane] = y.a1.v[4];
-    return f2_from_vec(f2_mul_lone_leaf(GPBC_PASS9(x.a0), GPBC_PASS9(x.a1), GPBC_PASS9(y.a0), y.a1.v[0], y.a1.v[1], y.a1.v[2], y.a1.v[3]));
-}
 template <bool NORM> __device__ __noinline__ i32x18 f2_sqr_leaf(GPBC_ARGS9(a), GPBC_ARGS9(b)) {
     return f2_to_vec(f2_sqr_core<NORM>(GPBC_PACK_F2(a, b)));
 }
@@ -158,9 +121,6 @@ GPBC_INLINE F2 f2_sqr(const F2 &x) { return f2_from_vec(f2_sqr_leaf<false>(GPBC_
 GPBC_INLINE F2 f2_sqr_n(const F2 &x) { return f2_from_vec(f2_sqr_leaf<true>(GPBC_PASS9(x.a0), GPBC_PASS9(x.a1))); }
 #else
 GPBC_INLINE Fe fe_mul2_l(const Fe &a, const Fe &b, const Fe &c, const Fe &d) { return fe_mul_core<true>(a, b, c, d); }
-GPBC_INLINE Fe fe_mul2_w(const Fe &a, const Fe &b, const Fe &c, const Fe &d) { Fe r, u; fe_mul_rows<true, false>(r, u, a, b, c, d, a, b, c, d); return r; }
-GPBC_INLINE Fe fe_mul_w(const Fe &a, const Fe &b) { Fe r, u; fe_mul_rows<false, false>(r, u, a, b, a, b, a, b, a, b); return r; }
-GPBC_INLINE F2 f2_mul_w(const F2 &x, const F2 &y) { F2 r; fe_mul_rows<true, true>(r.a0, r.a1, x.a0, y.a0, fe_neg(x.a1), y.a1, x.a0, y.a1, x.a1, y.a0); return r; }
 GPBC_INLINE F2 f2_mul(const F2 &x, const F2 &y) { return f2_mul_core<false>(x, y); }
 GPBC_INLINE F2 f2_mul_nn(const F2 &x, const F2 &y) { return f2_mul_core<true>(x, y); }      // both operands un-normalised sums
 GPBC_INLINE F2 f2_sqr(const F2 &x) { return f2_sqr_core<false>(x); }

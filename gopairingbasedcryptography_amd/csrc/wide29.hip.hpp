@@ -40,11 +40,11 @@ GPBC_INLINE int w2t(int k) { return (k >> 1) + 3 * (k & 1); }      // coefficien
 // ---- half products: lane (product p, half h) of a product phase
 // h = 0: a0 b0 - a1 b1      h = 1: a0 b1 + a1 b0          (a, b N-class)
 GPBC_INLINE Fe wide_half_mul(const F2 &a, const F2 &b, bool h) {
-    return fe_mul2_w(a.a0, fe_sel(h, b.a1, b.a0), fe_sel(h, a.a1, fe_neg(a.a1)), fe_sel(h, b.a0, b.a1));
+    return fe_mul2_l(a.a0, fe_sel(h, b.a1, b.a0), fe_sel(h, a.a1, fe_neg(a.a1)), fe_sel(h, b.a0, b.a1));
 }
 // h = 0: (x0 + x1)(x0 - x1)      h = 1: (2 x0) x1          (x normalised: a single Fp product takes one operand with limbs up to 2^30)
 GPBC_INLINE Fe wide_half_sqr(const F2 &x, bool h) {
-    return fe_mul_w(fe_sel(h, fe_dbl(x.a0), fe_add(x.a0, x.a1)), fe_sel(h, x.a1, fe_sub(x.a0, x.a1)));
+    return fe_mul(fe_sel(h, fe_dbl(x.a0), fe_add(x.a0, x.a1)), fe_sel(h, x.a1, fe_sub(x.a0, x.a1)));
 }
 // one component of (9 + i)(m + o i) seen from the lane that holds `mine`: 9 a0 - a1 (h = 0) or 9 a1 + a0 (h = 1); not normalised
 GPBC_INLINE Fe wide_xi_half(const Fe &mine, const Fe &other, bool h) {
@@ -81,7 +81,7 @@ template <class M, class Term> GPBC_INLINE void wide_recombine(M &m, int dst, in
 // dst = a * b.  Schoolbook over the w-basis: c_k = sum_{i+j=k} a_i b_j + xi sum_{i+j=k+6} a_i b_j.  (36 products: 72 halves would
 // need a second wave, so this one keeps whole F2 products on 36 lanes.)
 template <class M> GPBC_INLINE void wide_mul(M &m, int dst, int a, int b) {
-    m.run(36, [&](int l) { const int i = l / 6, j = l % 6; m.st(W_PROD + l, f2_mul_w(m.ld(a + w2t(i)), m.ld(b + w2t(j)))); });
+    m.run(36, [&](int l) { const int i = l / 6, j = l % 6; m.st(W_PROD + l, f2_mul(m.ld(a + w2t(i)), m.ld(b + w2t(j)))); });
     wide_recombine(m, dst, 6, [](int k, int i, int &slot, bool &wraps) {
         int j = k - i;
         wraps = j < 0;

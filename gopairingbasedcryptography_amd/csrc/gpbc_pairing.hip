@@ -303,6 +303,22 @@ __device__ __forceinline__ void wide_slot_store(w128 *mem, int slot, const F2 &v
 struct WideLds {
     w128 *mem;
     int lane;                                                // lane number inside the wave
+    // limb-parallel phases (wide29.hip.hpp: wide_cyclo_out_limbs): lane = component * NL + limb
+    static constexpr bool LIMB_PARALLEL = true;
+    __device__ __forceinline__ int comp() const { return lane / NL; }
+    __device__ __forceinline__ int limb() const { return lane % NL; }
+    __device__ __forceinline__ int32_t p_limb() const {      // this lane's limb of p
+        constexpr int32_t P[NL] = F29_P;
+        const int i = limb();
+        int32_t r = P[0];
+#pragma unroll
+        for (int j = 1; j < NL; j++) r = i == j ? P[j] : r;
+        return r;
+    }
+    __device__ __forceinline__ int32_t ldw(int slot, int h, int i) const { return reinterpret_cast<const int32_t *>(mem)[(slot * 6 + 3 * h) * 4 + i]; }
+    __device__ __forceinline__ void stw(int slot, int h, int i, int32_t v) const { reinterpret_cast<int32_t *>(mem)[(slot * 6 + 3 * h) * 4 + i] = v; }
+    __device__ __forceinline__ static int32_t below(int32_t v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, true); }   // the value of lane - 1 (wave_shr:1)
+    __device__ __forceinline__ int32_t from_top(int32_t v) const { return __builtin_amdgcn_ds_bpermute((comp() * NL + NL - 1) * 4, v); }   // ... of the lane that holds the component's top limb
     __device__ __forceinline__ F2 ld(int slot) const { return wide_slot_load(mem, slot); }
     __device__ __forceinline__ void st(int slot, const F2 &v) const { wide_slot_store(mem, slot, v); }
     __device__ __forceinline__ Fe ldh(int slot, int h) const { return wide_half_load(mem, slot, h); }

@@ -50,30 +50,53 @@ GPBC_INLINE Fe wide_half_sqr(const F2 &x, bool h) {
 GPBC_INLINE Fe wide_xi_half(const Fe &mine, const Fe &other, bool h) {
     return fe_add(fe_add(fe_mul8_norm(mine), mine), fe_sel(h, other, fe_neg(other)));
 }
-// Recombination of product halves into the six coefficients of dst, in two phases:
-//   24 lanes (coefficient k, lo / hi, half): the sum of the terms of that kind, term(k, t) -> product slot and whether it wraps
-//   (i + j >= 6: multiplied by xi), normalised after every third term;
-//   12 lanes (k, half): lo + xi hi, normalised and value-reduced.
+// Recombination of product halves into the six coefficients of dst.  term(k, t) -> product slot and whether it wraps (i + j >= 6:
+// multiplied by xi).  Per output half (k, h):  lo = sum of the un-wrapped terms' half h,  hi = sum of the wrapped terms (both halves:
+// the xi step mixes them), each normalised after every third term and at the end;  out = reduce(norm(lo + norm(xi hi))).
+// Device: ONE LIMB PER LANE (lane = output half * NL + limb, two passes of 54 lanes: k < 3, k >= 3) — a lone wave pays ~5 cycles per
+// instruction, and per limb a normalisation is five instructions instead of 27 (see wide_cyclo_out_limbs).  Host harness: the same
+// sequence on whole elements, limb for limb the same values.
 template <class M, class Term> GPBC_INLINE void wide_recombine(M &m, int dst, int n_terms, Term &&term) {
-    m.run(24, [&](int L) {
-        const int k = L >> 2, h = L & 1;
-        const bool want_hi = (L & 2) != 0;
-        Fe acc = fe_zero();
+    if constexpr (M::LIMB_PARALLEL) {
+        for (int pass = 0; pass < 2; pass++)
+            m.run(6 * NL, [&](int) {
+                const int o = m.comp(), i = m.limb(), k = 3 * pass + (o >> 1), h = o & 1;
+                const int32_t low = i == NL - 1 ? -1 : LMASK, low26 = i == NL - 1 ? -1 : (1 << (LB - 3)) - 1, carry_in = i == 0 ? 0 : -1;
+                auto norm = [&](int32_t v) { return (v & low) + ((m.below(v) >> LB) & carry_in); };
+                auto mul8n = [&](int32_t v) { return ((v & low26) << 3) + ((m.below(v) >> (LB - 3)) & carry_in); };
+                int32_t lo = 0, hi = 0, ho = 0;
+                for (int t = 0; t < n_terms; t++) {
+                    int slot;
+                    bool wraps;
+                    term(k, t, slot, wraps);
+                    const int32_t mine = m.ldw(slot, h, i), other = m.ldw(slot, 1 - h, i);
+                    lo += wraps ? 0 : mine; hi += wraps ? mine : 0; ho += wraps ? other : 0;
+                    if (t % 3 == 2) { lo = norm(lo); hi = norm(hi); ho = norm(ho); }
+                }
+                lo = norm(lo); hi = norm(hi); ho = norm(ho);
+                const int32_t w = norm(lo + norm(mul8n(hi) + hi + (h ? ho : -ho)));
+                const int32_t kp = (int32_t)rintf((float)m.from_top(w) * (1.0f / (float)f29_p(NL - 1)));
+                const int64_t prod = (int64_t)kp * (int64_t)m.p_limb();
+                const int32_t plo = (int32_t)(prod & LMASK), phi = (int32_t)(prod >> LB);
+                m.stw(dst + w2t(k), h, i, w - (i == NL - 1 ? (int32_t)prod : plo) - (m.below(phi) & carry_in));
+            });
+        return;
+    }
+    m.run(12, [&](int L) {
+        const int k = L >> 1;
+        const bool h = L & 1;
+        Fe lo = fe_zero(), hi = fe_zero(), ho = fe_zero();
         for (int t = 0; t < n_terms; t++) {
             int slot;
             bool wraps;
             term(k, t, slot, wraps);
-            acc = fe_add(acc, fe_sel(wraps == want_hi, m.ldh(slot, h), fe_zero()));
-            if (t % 3 == 2) acc = fe_norm(acc);
+            const Fe mine = m.ldh(slot, h), other = m.ldh(slot, 1 - h);
+            lo = fe_add(lo, fe_sel(wraps, fe_zero(), mine)); hi = fe_add(hi, fe_sel(wraps, mine, fe_zero())); ho = fe_add(ho, fe_sel(wraps, other, fe_zero()));
+            if (t % 3 == 2) { lo = fe_norm(lo); hi = fe_norm(hi); ho = fe_norm(ho); }
         }
-        m.sth((want_hi ? W_HI : W_LO) + k, h, fe_norm(acc));
-    });
-    m.run(12, [&](int L) {
-        const int k = L >> 1;
-        const bool h = L & 1;
-        const F2 hi = m.ld(W_HI + k);
-        const Fe x = fe_norm(wide_xi_half(h ? hi.a1 : hi.a0, h ? hi.a0 : hi.a1, h));
-        m.sth(dst + w2t(k), h, fe_reduce(fe_norm(fe_add(m.ldh(W_LO + k, h), x))));
+        lo = fe_norm(lo); hi = fe_norm(hi); ho = fe_norm(ho);
+        const Fe x = fe_norm(wide_xi_half(hi, ho, h));
+        m.sth(dst + w2t(k), h, fe_reduce_arith(fe_norm(fe_add(lo, x))));
     });
 }
 
@@ -102,6 +125,38 @@ template <class M> GPBC_INLINE void wide_mul_line(M &m, int dst, int a, int line
         slot = W_PROD + i * 3 + t;
     });
 }
+// The output step of wide_cyclo_sqr with one limb per lane (device only; see there).  C0: the pass for k < 3, else k >= 3.
+template <bool C0, class M> GPBC_INLINE void wide_cyclo_out_limbs(M &m, int dst, int a) {
+    if constexpr (M::LIMB_PARALLEL) {
+        m.run(6 * NL, [&](int L) {
+            const int o = m.comp(), i = m.limb(), kk = o >> 1, h = o & 1, k = (C0 ? 0 : 3) + kk;
+            const int A = C0 ? (kk == 0 ? 4 : kk == 1 ? 2 : 5) : (kk == 0 ? 5 : kk == 1 ? 4 : 2);
+            const int B = C0 ? (kk == 0 ? 0 : kk == 1 ? 3 : 1) : (kk == 0 ? 1 : kk == 1 ? 0 : 3);
+            const int32_t low = i == NL - 1 ? -1 : LMASK, low26 = i == NL - 1 ? -1 : (1 << (LB - 3)) - 1, carry_in = i == 0 ? 0 : -1;
+            auto norm = [&](int32_t v) { return (v & low) + ((m.below(v) >> LB) & carry_in); };                       // fe_norm
+            auto mul8n = [&](int32_t v) { return ((v & low26) << 3) + ((m.below(v) >> (LB - 3)) & carry_in); };       // fe_mul8_norm
+            int32_t mine, other, t;
+            if constexpr (C0) {
+                mine = m.ldw(W_PROD + A, h, i); other = m.ldw(W_PROD + A, 1 - h, i);
+            } else {
+                const int S = kk == 0 ? 8 : kk == 1 ? 6 : 7;
+                mine = norm(m.ldw(W_PROD + S, h, i) - m.ldw(W_PROD + A, h, i) - m.ldw(W_PROD + B, h, i));              // d, this half
+                other = norm(m.ldw(W_PROD + S, 1 - h, i) - m.ldw(W_PROD + A, 1 - h, i) - m.ldw(W_PROD + B, 1 - h, i)); // d, the other half
+            }
+            const int32_t X = norm(mul8n(mine) + mine + (h ? other : -other));                                        // one component of xi (mine + other i)
+            if constexpr (C0) t = norm(X + m.ldw(W_PROD + B, h, i));
+            else t = kk == 0 ? X : mine;
+            const int32_t x = m.ldw(a + k, h, i);
+            const int32_t dd = norm(t + (C0 ? -x : x));
+            const int32_t w = norm(2 * dd + t);
+            // fe_reduce_arith: k p with k from the top limb of w, this lane's limb of it from one product, the high part from the limb below
+            const int32_t kp = (int32_t)rintf((float)m.from_top(w) * (1.0f / (float)f29_p(NL - 1)));
+            const int64_t prod = (int64_t)kp * (int64_t)m.p_limb();
+            const int32_t lo = (int32_t)(prod & LMASK), hi = (int32_t)(prod >> LB);
+            m.stw(dst + k, h, i, w - (i == NL - 1 ? (int32_t)prod : lo) - (m.below(hi) & carry_in));
+        });
+    }
+}
 // dst = a^2 for a in the cyclotomic subgroup (Granger-Scott; the formulas of f12_cyclo_sqr_t): nine squarings as 18 halves, six
 // outputs as 12.
 template <class M> GPBC_INLINE void wide_cyclo_sqr(M &m, int dst, int a) {
@@ -112,8 +167,21 @@ template <class M> GPBC_INLINE void wide_cyclo_sqr(M &m, int dst, int a) {
         const F2 x = m.ld(a + u), y = m.ld(a + v);
         m.sth(W_PROD + l, L & 1, wide_half_sqr(f2_norm(f2_sel(l < 6, x, f2_add(x, y))), L & 1));
     });
-    // twelve output halves, ONE instruction stream (a per-lane branch would run both forms one after the other):
+    // twelve output halves:
     //   k < 3:  C0.b_k' = 3 (xi S[A] + S[B]) - 2 x          k >= 3:  C1.b' = 3 [xi] (S[sum] - S[A] - S[B]) + 2 x   (xi for k = 3 only)
+    if constexpr (M::LIMB_PARALLEL) {
+        // Everything after the squares is LINEAR, and a lone wave pays ~5 cycles per instruction whatever it is: with one output half
+        // per lane this phase was ~350 instructions on 12 lanes — as long as the squarings themselves (profiles/r04_latency_phases.txt).
+        // One LIMB per lane instead: lane (o, i) holds limb i of output half o; a normalisation is "keep the low bits, add the carry of
+        // the limb below", i.e. one neighbour exchange (m.below) and four instructions, the value reduction takes its multiplier k from
+        // the lane of the top limb (m.from_top) and its limb of k p from one 64-bit product.  Limb for limb the values of the Fe-level
+        // form in the other branch (fe_norm, fe_mul8_norm, fe_reduce_arith written out per limb) — that branch is what the interval
+        // harness runs.  Two passes of 54 lanes: k < 3, then k >= 3 (no per-lane choice between the two formulas).
+        wide_cyclo_out_limbs<true>(m, dst, a);
+        wide_cyclo_out_limbs<false>(m, dst, a);
+        return;
+    }
+    // ONE instruction stream (a per-lane branch would run both forms one after the other)
     m.run(12, [&](int L) {
         const int k = L >> 1;
         const bool h = L & 1, c0 = k < 3;
@@ -129,7 +197,7 @@ template <class M> GPBC_INLINE void wide_cyclo_sqr(M &m, int dst, int a) {
         // 3 t -+ 2 x with the value reduction at the end
         const Fe x = m.ldh(a + k, h);
         const Fe dd = fe_norm(fe_add(t, fe_sel(c0, fe_neg(x), x)));
-        m.sth(dst + k, h, fe_reduce(fe_norm(fe_add(fe_dbl(dd), t))));
+        m.sth(dst + k, h, fe_reduce_arith(fe_norm(fe_add(fe_dbl(dd), t))));
     });
 }
 template <class M> GPBC_INLINE void wide_copy(M &m, int dst, int a) { m.run(6, [&](int k) { m.st(dst + k, m.ld(a + k)); }); }

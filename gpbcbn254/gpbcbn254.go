@@ -85,6 +85,7 @@ func InitCollectives() error {
 // Shutdown releases the library's device memory and communicators.
 func Shutdown() error {
 	defer pin()()
+	destroyGeneratorTables() // before the devices go: the tables live in their HBM
 	return status(C.gpbc_shutdown())
 }
 
@@ -180,27 +181,51 @@ func G1ScalarMultiplication(p, a *bn254.G1Affine, s *big.Int) *bn254.G1Affine {
 
 // Fixed-base window tables of the two generators (1 MB / 2 MB of HBM), built on the first ScalarMultiplicationBase call:
 // 32 mixed additions per multiplication instead of the variable-base kernel's doublings.
+// A mutex, not a sync.Once: a Once whose function panics (a call before Init, a failed table build) is spent for good and would leave
+// nil handles behind for every later call.  The handles are set only when both tables exist, a failed attempt is retried by the
+// next call, and Shutdown destroys them so that Init after Shutdown builds fresh ones.
 var (
-	genOnce          sync.Once
+	genMu            sync.Mutex
 	g1Table, g2Table *C.gpbc_fixed_base
 )
 
-func generatorTables() {
-	genOnce.Do(func() {
+func generatorTables() (*C.gpbc_fixed_base, *C.gpbc_fixed_base) {
+	genMu.Lock()
+	defer genMu.Unlock()
+	if g1Table == nil || g2Table == nil {
 		_, _, g1, g2 := bn254.Generators()
-		must(C.gpbc_g1_fixed_base_create(unsafe.Pointer(&g1), 1, &g1Table))
-		must(C.gpbc_g2_fixed_base_create(unsafe.Pointer(&g2), 1, &g2Table))
-	})
+		var t1, t2 *C.gpbc_fixed_base
+		must(C.gpbc_g1_fixed_base_create(unsafe.Pointer(&g1), 1, &t1))
+		if rc := C.gpbc_g2_fixed_base_create(unsafe.Pointer(&g2), 1, &t2); rc != 0 {
+			msg := C.GoString(C.gpbc_last_error())
+			C.gpbc_fixed_base_destroy(t1)
+			panic("gpbcbn254: " + msg)
+		}
+		g1Table, g2Table = t1, t2
+	}
+	return g1Table, g2Table
+}
+
+func destroyGeneratorTables() {
+	genMu.Lock()
+	defer genMu.Unlock()
+	if g1Table != nil {
+		C.gpbc_fixed_base_destroy(g1Table)
+	}
+	if g2Table != nil {
+		C.gpbc_fixed_base_destroy(g2Table)
+	}
+	g1Table, g2Table = nil, nil
 }
 
 // G1ScalarMultiplicationBase replaces new(bn254.G1Affine).ScalarMultiplicationBase(s)
 // (cpabe/bsw07/bsw07_cpabe.go:69; bibe/afp25_bibe/afp25_bibe.go:160).
 func G1ScalarMultiplicationBase(p *bn254.G1Affine, s *big.Int) *bn254.G1Affine {
 	defer pin()()
-	generatorTables()
+	t1, _ := generatorTables()
 	var k [32]byte
 	scalarBytes(s, &k)
-	must(C.gpbc_fixed_base_msm(g1Table, unsafe.Pointer(&k[0]), 1, unsafe.Pointer(p)))
+	must(C.gpbc_fixed_base_msm(t1, unsafe.Pointer(&k[0]), 1, unsafe.Pointer(p)))
 	return p
 }
 
@@ -220,10 +245,10 @@ func G2ScalarMultiplication(p, a *bn254.G2Affine, s *big.Int) *bn254.G2Affine {
 // (cpabe/bsw07/bsw07_cpabe.go:73; bibe/afp25_bibe/afp25_bibe.go:164-165).
 func G2ScalarMultiplicationBase(p *bn254.G2Affine, s *big.Int) *bn254.G2Affine {
 	defer pin()()
-	generatorTables()
+	_, t2 := generatorTables()
 	var k [32]byte
 	scalarBytes(s, &k)
-	must(C.gpbc_fixed_base_msm(g2Table, unsafe.Pointer(&k[0]), 1, unsafe.Pointer(p)))
+	must(C.gpbc_fixed_base_msm(t2, unsafe.Pointer(&k[0]), 1, unsafe.Pointer(p)))
 	return p
 }
 

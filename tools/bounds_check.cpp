@@ -108,6 +108,7 @@ template <class F, class LoadA, class StoreA> static void msm_host(const uint8_t
 // host memory policy of the latency ("wide") form, csrc/wide29.hip.hpp: the slots are interval-carrying values, the lanes of a
 // phase run one after the other and their stores land when the phase ends (what the barrier does on the device)
 struct WideHost {
+    static constexpr bool LIMB_PARALLEL = false;          // the device spreads some linear phases over one limb per lane; the host runs their Fe-level form
     std::vector<F2> s = std::vector<F2>(W_SLOTS, f2_zero());
     std::vector<std::pair<int, F2>> pending;
     std::vector<std::tuple<int, int, Fe>> pending_half;

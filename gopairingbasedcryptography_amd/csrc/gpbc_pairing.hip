@@ -300,9 +300,15 @@ __device__ __forceinline__ F2 wide_slot_load(const w128 *mem, int slot) { return
 __device__ __forceinline__ void wide_slot_store(w128 *mem, int slot, const F2 &v) { wide_half_store(mem, slot, 0, v.a0); wide_half_store(mem, slot, 1, v.a1); }
 // The phases of ONE WAVE: its LDS instructions execute in program order, so a phase's stores are visible to the next phase's loads
 // of any lane of the same wave; the fence / wave barrier only keeps the compiler from moving LDS accesses across the phase boundary.
+// A workgroup of the exponentiation / product kernels may bring a HELPER wave (128 threads instead of 64): it sits out every phase
+// except the product phase of wide_mul (run2), where the 72 halves of the 36 F2 products go to 72 lanes of the two waves instead of
+// 36 whole products to one — a lone wave issues one MAD per ~9 cycles, so that phase is halved.  Calls of more than 1 024 elements
+// come without it (two waves per element would need a second round of the chip).
 struct WideLds {
     w128 *mem;
     int lane;                                                // lane number inside the wave
+    int helper = 0, n_waves = 1;                             // helper: this wave only takes part in run2 phases
+    __device__ __forceinline__ int waves() const { return n_waves; }
     // limb-parallel phases (wide29.hip.hpp: wide_cyclo_out_limbs): lane = component * NL + limb
     static constexpr bool LIMB_PARALLEL = true;
     __device__ __forceinline__ int comp() const { return lane / NL; }
@@ -324,12 +330,49 @@ struct WideLds {
     __device__ __forceinline__ Fe ldh(int slot, int h) const { return wide_half_load(mem, slot, h); }
     __device__ __forceinline__ void sth(int slot, int h, const Fe &v) const { wide_half_store(mem, slot, h, v); }
     template <class B> __device__ __forceinline__ void run(int n, B &&body) const {
-        if (lane < n) body(lane);
+        if (!helper && lane < n) body(lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    // a phase of BOTH waves (n <= 128 lanes; only where waves() == 2): workgroup barriers on both sides — every wave of the workgroup
+    // walks the same (uniform) control flow, so both reach them
+    // one-limb-per-lane operations of the linear phases (wide29.hip.hpp "linear phases"): lane = component * NL + limb
+    struct LimbOps {
+        using V = int32_t;
+        const WideLds &m;
+        int i;
+        int32_t low, carry_in, p_i;
+        __device__ __forceinline__ explicit LimbOps(const WideLds &w) : m(w), i(w.limb()), low(w.limb() == NL - 1 ? -1 : LMASK), carry_in(w.limb() == 0 ? 0 : -1), p_i(w.p_limb()) {}
+        __device__ __forceinline__ V ld(int slot, int h) const { return m.ldw(slot, h, i); }
+        __device__ __forceinline__ void st(int slot, int h, V v) const { m.stw(slot, h, i, v); }
+        __device__ __forceinline__ static V add(V a, V b) { return a + b; }
+        __device__ __forceinline__ static V sub(V a, V b) { return a - b; }
+        __device__ __forceinline__ static V dbl(V a) { return a + a; }
+        __device__ __forceinline__ static V neg(V a) { return -a; }
+        __device__ __forceinline__ static V sel(bool c, V a, V b) { return c ? a : b; }
+        __device__ __forceinline__ V norm(V v) const { return (v & low) + ((below(v) >> LB) & carry_in); }                  // fe_norm
+        __device__ __forceinline__ V halve(V v) const {                                                                    // fe_halve
+            const int32_t odd = -(__builtin_amdgcn_ds_bpermute(m.comp() * NL * 4, v) & 1);                                   // parity of the value = parity of limb 0
+            const int32_t t = v + (p_i & odd);
+            const int32_t up = __builtin_amdgcn_update_dpp(0, t, 0x130, 0xF, 0xF, true);                                     // the limb above (wave_shl:1)
+            return (t >> 1) + (i == NL - 1 ? 0 : (up & 1) << (LB - 1));
+        }
+    };
+    template <class B> __device__ __forceinline__ void limbs(int n_comp, B &&body) const {
+        run(n_comp * NL, [&](int) { LimbOps o(*this); body(o, comp()); });
+    }
+    __device__ __forceinline__ void sync_waves() const { if (n_waves == 2) __syncthreads(); }    // before control flow that depends on LDS contents
+    template <class B> __device__ __forceinline__ void run2(int n, B &&body) const {
+        __syncthreads();
+        const int l = helper * 64 + lane;
+        if (l < n) body(l);
+        __syncthreads();
+    }
 };
+#define GPBC_KERNEL_WIDE __global__ void __launch_bounds__(128, GPBC_WAVES_PER_SIMD)
+constexpr size_t WIDE_HELPER_MAX = 1024;                     // elements per call up to which the helper wave comes along
+static inline unsigned wide_threads(size_t n) { return n <= WIDE_HELPER_MAX ? 128u : 64u; }
 // Two waves per pairing: wave 0 walks the G2 point and leaves each of the 88 lines in an LDS ring (21 KB), wave 1 runs the Fp12
 // accumulator and takes line j as soon as the ring's counter says it is there — the two chains (~235 k and ~180 k instructions) run
 // side by side on two SIMDs instead of one after the other.  Both waves belong to one workgroup, so both are resident: the consumer's
@@ -388,11 +431,11 @@ GPBC_KERNEL k_q_lines_wide(const uint8_t *__restrict__ Q, int32_t *__restrict__ 
         });
     });
 }
-GPBC_KERNEL k_final_exp_wide(const uint8_t *f_in, uint8_t *gt_out, size_t n) {
+GPBC_KERNEL_WIDE k_final_exp_wide(const uint8_t *f_in, uint8_t *gt_out, size_t n) {
     __shared__ w128 w_mem[W_SLOTS * 6];
     const size_t i = blockIdx.x;
     if (i >= n) return;
-    const WideLds m{w_mem, (int)threadIdx.x};
+    const WideLds m{w_mem, (int)(threadIdx.x & 63), (int)(threadIdx.x >> 6), (int)(blockDim.x >> 6)};
     m.run(6, [&](int k) { m.st(k, f2_load(f_in + i * GPBC_GT_BYTES + 64 * k)); });
     wide_final_exp(m);
     m.run(6, [&](int k) { f2_store(gt_out + i * GPBC_GT_BYTES + 64 * k, m.ld(k)); });
@@ -401,7 +444,7 @@ GPBC_KERNEL k_final_exp_wide(const uint8_t *f_in, uint8_t *gt_out, size_t n) {
 // Long segments of a latency call (one BSW07 ciphertext is 513 pairs, a BB04 identity 257): `fold` wavefronts per segment each
 // multiply one residue class of the segment's Miller values — lo + s, lo + s + fold, ... — and leave the product in place at lo + s,
 // so that the wavefront of k_segment_final_exp_wide multiplies `fold` values instead of the whole run.  Same clamping of the table.
-GPBC_KERNEL k_segment_fold_wide(uint8_t *f, const uint64_t *__restrict__ seg_off, size_t uniform_len, size_t k, size_t n_vals, unsigned fold) {
+GPBC_KERNEL_WIDE k_segment_fold_wide(uint8_t *f, const uint64_t *__restrict__ seg_off, size_t uniform_len, size_t k, size_t n_vals, unsigned fold) {
     __shared__ w128 w_mem[W_SLOTS * 6];
     const size_t j = blockIdx.x / fold;
     const uint64_t s = blockIdx.x % fold;
@@ -409,8 +452,8 @@ GPBC_KERNEL k_segment_fold_wide(uint8_t *f, const uint64_t *__restrict__ seg_off
     uint64_t lo = seg_off ? seg_off[j] : j * uniform_len, hi = seg_off ? seg_off[j + 1] : (j + 1) * uniform_len;   // no table: equal runs
     if (hi > n_vals) hi = n_vals;
     if (lo > hi) lo = hi;
-    if (hi - lo <= s + fold) return;                        // this class holds at most one value: it stays where it is
-    const WideLds m{w_mem, (int)threadIdx.x};
+    if (hi - lo <= s + fold) return;                        // this class holds at most one value: it stays where it is (the same for the whole workgroup)
+    const WideLds m{w_mem, (int)(threadIdx.x & 63), (int)(threadIdx.x >> 6), (int)(blockDim.x >> 6)};
     m.run(6, [&](int c) { m.st(c, f2_load(f + (lo + s) * GPBC_GT_BYTES + 64 * c)); });
     for (uint64_t i = lo + s + fold; i < hi; i += fold) {
         m.run(6, [&](int c) { m.st(wv(1) + c, f2_load(f + i * GPBC_GT_BYTES + 64 * c)); });
@@ -426,12 +469,12 @@ GPBC_KERNEL k_segment_fold_wide(uint8_t *f, const uint64_t *__restrict__ seg_off
 // `fold` values.
 // `ok_out` (may be null): 1 where the segment's value is GT's one — PairingCheck's answer, taken from the canonical words the lanes
 // are about to store (a later k_gt_is_one would have to read them back, and in a small call they live in host memory).
-GPBC_KERNEL k_segment_final_exp_wide(const uint8_t *__restrict__ f, const uint64_t *__restrict__ seg_off, size_t uniform_len, uint8_t *__restrict__ out, size_t k, size_t n_vals,
+GPBC_KERNEL_WIDE k_segment_final_exp_wide(const uint8_t *__restrict__ f, const uint64_t *__restrict__ seg_off, size_t uniform_len, uint8_t *__restrict__ out, size_t k, size_t n_vals,
                                      uint64_t *__restrict__ echo, unsigned fold, uint8_t *__restrict__ ok_out) {
     __shared__ w128 w_mem[W_SLOTS * 6];
     const size_t j = blockIdx.x;
     if (j >= k) return;
-    const WideLds m{w_mem, (int)threadIdx.x};
+    const WideLds m{w_mem, (int)(threadIdx.x & 63), (int)(threadIdx.x >> 6), (int)(blockDim.x >> 6)};
     uint64_t lo = seg_off ? seg_off[j] : j * uniform_len, hi = seg_off ? seg_off[j + 1] : (j + 1) * uniform_len;
     if (hi > n_vals) hi = n_vals;
     if (lo > hi) lo = hi;
@@ -576,11 +619,11 @@ GPBC_KERNEL k_gt_exp(const uint8_t *__restrict__ x, const uint8_t *__restrict__ 
 }
 
 // the same for the calls of the latency path: one element per wavefront (wide_exp256)
-GPBC_KERNEL k_gt_exp_wide(const uint8_t *__restrict__ x, const uint8_t *__restrict__ kk, uint8_t *__restrict__ out, size_t n) {
+GPBC_KERNEL_WIDE k_gt_exp_wide(const uint8_t *__restrict__ x, const uint8_t *__restrict__ kk, uint8_t *__restrict__ out, size_t n) {
     __shared__ w128 w_mem[W_SLOTS * 6];
     const size_t i = blockIdx.x;
     if (i >= n) return;
-    const WideLds m{w_mem, (int)threadIdx.x};
+    const WideLds m{w_mem, (int)(threadIdx.x & 63), (int)(threadIdx.x >> 6), (int)(blockDim.x >> 6)};
     uint32_t k[8];
 #pragma unroll
     for (int w = 0; w < 8; w++) k[w] = __builtin_amdgcn_readfirstlane(reinterpret_cast<const uint32_t *>(kk + i * GPBC_SCALAR_BYTES)[w]);
@@ -669,7 +712,7 @@ int gpbc_final_exp_dev(const void *d_f, size_t n, void *d_gt_out, void *stream) 
     // (two rounds of the chip still beat the lane-pair kernel's 2.6 ms floor: 3 072 / 4 096 values 1.38 / 1.75 ms; 6 144: 2.54 — even.
     // The Miller loop's switch-over stays at one round: its wavefront form holds 768 pairings at a time.)
     if (n <= 2 * g_wide_max.load()) {
-        k_final_exp_wide<<<(unsigned)n, BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_f, (uint8_t *)d_gt_out, n);
+        k_final_exp_wide<<<(unsigned)n, wide_threads(n), 0, (hipStream_t)stream>>>((const uint8_t *)d_f, (uint8_t *)d_gt_out, n);
         profile_mark("k_final_exp_wide", (hipStream_t)stream);
         return check_launch("k_final_exp_wide");
     }
@@ -707,11 +750,11 @@ static int segment_fold_passes(uint8_t *vals, const uint64_t *d_seg_off, size_t 
 static int segments_wide(uint8_t *vals, const uint64_t *d_seg_off, size_t uniform_len, size_t k, size_t n_vals, uint8_t *d_gt_out, uint64_t *d_echo, hipStream_t st, uint8_t *d_ok = nullptr) {
     const unsigned fold = n_vals >= 128 * k ? 16u : n_vals >= 32 * k ? 8u : 0u;
     if (fold) {
-        k_segment_fold_wide<<<(unsigned)(k * fold), BLOCK, 0, st>>>(vals, d_seg_off, uniform_len, k, n_vals, fold);
+        k_segment_fold_wide<<<(unsigned)(k * fold), wide_threads(k * fold), 0, st>>>(vals, d_seg_off, uniform_len, k, n_vals, fold);
         TRY(check_launch("k_segment_fold_wide"));
         profile_mark("k_segment_fold_wide", st);
     }
-    k_segment_final_exp_wide<<<(unsigned)k, BLOCK, 0, st>>>(vals, d_seg_off, uniform_len, d_gt_out, k, n_vals, d_echo, fold, d_ok);
+    k_segment_final_exp_wide<<<(unsigned)k, wide_threads(k), 0, st>>>(vals, d_seg_off, uniform_len, d_gt_out, k, n_vals, d_echo, fold, d_ok);
     TRY(check_launch("k_segment_final_exp_wide"));
     profile_mark("k_segment_final_exp_wide", st);
     return GPBC_OK;
@@ -764,7 +807,7 @@ int gpbc_gt_exp_batch_dev(const void *d_x, const void *d_k, size_t n, void *d_ou
     // one round of the chip holds 2 048 wavefronts (1.1 ms per round when full), the lane-pair kernel needs 3.6 ms whatever the size
     // below 65 536: measured 2 048 / 4 096 / 8 192 elements 1.09 / 2.45 / 4.23 ms against 3.6 — two rounds is where the wavefront form stops winning
     if (n <= 2 * g_wide_max.load()) {
-        k_gt_exp_wide<<<(unsigned)n, BLOCK, 0, st>>>((const uint8_t *)d_x, (const uint8_t *)d_k, (uint8_t *)d_out, n);
+        k_gt_exp_wide<<<(unsigned)n, wide_threads(n), 0, st>>>((const uint8_t *)d_x, (const uint8_t *)d_k, (uint8_t *)d_out, n);
         TRY(check_launch("k_gt_exp_wide"));
         profile_mark("k_gt_exp_wide", st);
         return GPBC_OK;
@@ -891,7 +934,7 @@ static int small_gt_run(int OP, CallLane &lane, SmallCall *const *calls, size_t 
         n0 += r.units;
     }
     if (OP == 3) {
-        k_gt_exp_wide<<<(unsigned)N, BLOCK, 0, lane.stream>>>(lane.d_pin + oA, lane.d_pin + oB, lane.d_pin + oO, N);
+        k_gt_exp_wide<<<(unsigned)N, wide_threads(N), 0, lane.stream>>>(lane.d_pin + oA, lane.d_pin + oB, lane.d_pin + oO, N);
         TRY(check_launch("k_gt_exp_wide"));
         profile_mark("k_gt_exp_wide", lane.stream);
     } else {

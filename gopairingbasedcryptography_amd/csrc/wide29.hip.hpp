@@ -32,10 +32,35 @@ constexpr int W_XP = W_TX + 10, W_YP = W_TX + 11;                               
 constexpr int W_L0 = W_TX + 12, W_L3 = W_TX + 13, W_L4 = W_TX + 14;              // the current line c0, c3, c4
 constexpr int W_G = W_TX + 15;                       // 12 scratch slots of the point steps
 constexpr int W_CL = W_G + 12;                       // the accumulator's copy of the line it is multiplying by (c0, c3, c4)
-constexpr int W_LO = W_CL + 3, W_HI = W_LO + 6;      // partial sums of a recombination: un-wrapped and wrapped (times xi) terms per coefficient
-constexpr int W_SLOTS = W_HI + 6;
+// operands the linear phases of the point steps leave, normalised, for the product rounds (the G2 walk's own: the accumulator wave never touches them)
+constexpr int W_YZ = W_CL + 3;                       // y + z of T
+constexpr int W_HN = W_YZ + 1, W_C3 = W_YZ + 2, W_J3 = W_YZ + 3, W_AH = W_YZ + 4, W_BF = W_YZ + 5, W_GG = W_YZ + 6;   // doubling: H, 3C, 3J, XY/2, B - F, (B + F)/2
+constexpr int W_HH = W_YZ + 7, W_GH = W_YZ + 8;      // addition: H, G - H
+constexpr int W_SLOTS = W_YZ + 9;
 constexpr int wv(int n) { return 6 * n; }
 GPBC_INLINE int w2t(int k) { return (k >> 1) + 3 * (k & 1); }      // coefficient of w^k -> tower slot offset (0,3,1,4,2,5)
+
+// ---- linear phases, ONE LIMB PER LANE.  A lone wave pays ~5 cycles per instruction whatever it is, so sums, normalisations and
+// halvings done on whole elements (27-40 instructions each, on a handful of lanes) cost as much as the products between them.  A linear
+// phase is written once as a function of an operations object `o` and a component number c (= output half: slot * 2 + half):
+//     m.limbs(n_components, [&](auto &o, int c) { ... o.ld(slot, h) ... o.add / sub / dbl / neg / sel / norm / halve ... o.st(slot, h, v); });
+// On the device `o` works on ONE limb (lane = c * NL + limb; a normalisation takes the carry from the lane below through a DPP
+// wave shift, a halving the parity bit from the lane above): WideLds::LimbOps in gpbc_pairing.hip.  Under the host harness `o` is
+// LimbOpsFe below: the same calls on whole elements with their tracked intervals — limb for limb the same values, so what the harness
+// proves holds for the device form.  At most 7 components per phase (63 lanes).
+template <class M> struct LimbOpsFe {
+    using V = Fe;
+    M &m;
+    V ld(int slot, int h) const { return m.ldh(slot, h); }
+    void st(int slot, int h, const V &v) const { m.sth(slot, h, v); }
+    static V add(const V &a, const V &b) { return fe_add(a, b); }
+    static V sub(const V &a, const V &b) { return fe_sub(a, b); }
+    static V dbl(const V &a) { return fe_dbl(a); }
+    static V neg(const V &a) { return fe_neg(a); }
+    static V sel(bool c, const V &a, const V &b) { return fe_sel(c, a, b); }
+    static V norm(const V &a) { return fe_norm(a); }
+    static V halve(const V &a) { return fe_halve(a); }
+};
 
 // ---- half products: lane (product p, half h) of a product phase
 // h = 0: a0 b0 - a1 b1      h = 1: a0 b1 + a1 b0          (a, b N-class)
@@ -104,7 +129,10 @@ template <class M, class Term> GPBC_INLINE void wide_recombine(M &m, int dst, in
 // dst = a * b.  Schoolbook over the w-basis: c_k = sum_{i+j=k} a_i b_j + xi sum_{i+j=k+6} a_i b_j.  (36 products: 72 halves would
 // need a second wave, so this one keeps whole F2 products on 36 lanes.)
 template <class M> GPBC_INLINE void wide_mul(M &m, int dst, int a, int b) {
-    m.run(36, [&](int l) { const int i = l / 6, j = l % 6; m.st(W_PROD + l, f2_mul(m.ld(a + w2t(i)), m.ld(b + w2t(j)))); });
+    if (m.waves() == 2)      // with the helper wave: 72 half products on 72 lanes (the same limbs as the whole products: r0 = a0 b0 - a1 b1, r1 = a0 b1 + a1 b0)
+        m.run2(72, [&](int L) { const int l = L >> 1, i = l / 6, j = l % 6; m.sth(W_PROD + l, L & 1, wide_half_mul(m.ld(a + w2t(i)), m.ld(b + w2t(j)), L & 1)); });
+    else
+        m.run(36, [&](int l) { const int i = l / 6, j = l % 6; m.st(W_PROD + l, f2_mul(m.ld(a + w2t(i)), m.ld(b + w2t(j)))); });
     wide_recombine(m, dst, 6, [](int k, int i, int &slot, bool &wraps) {
         int j = k - i;
         wraps = j < 0;
@@ -232,39 +260,49 @@ template <class M> GPBC_INLINE void wide_inv(M &m, int dst, int a, int tmp) {
 // ---- G2 steps on slots (formulas and names of g2_double_step / g2_add_step; every round is a set of independent F2 products, each
 // lane picking its operand SLOTS by its number — one instruction stream for all of them)
 template <class M> GPBC_INLINE void wide_double_step(M &m) {
-    // round 1: G0 = XY = x y, G1 = B = y^2, G2 = C = z^2, G3 = J = x^2, G4 = YZ = (y + z)^2
+    // round 1: G0 = XY = x y, G1 = B = y^2, G2 = C = z^2, G3 = J = x^2, G4 = YY = (y + z)^2 — y + z stands normalised in W_YZ (left by
+    // the step before), so every lane loads its two operands and multiplies
     m.run(10, [&](int L) {
         const int l = L >> 1;
-        const F2 z = m.ld(W_TZ);
-        const F2 a = m.ld(l == 0 || l == 3 ? W_TX : l == 2 ? W_TZ : W_TY), b = m.ld(l == 3 ? W_TX : l == 2 ? W_TZ : W_TY);
-        m.sth(W_G + l, L & 1, wide_half_mul(f2_norm(f2_sel(l == 4, f2_add(a, z), a)), f2_norm(f2_sel(l == 4, f2_add(b, z), b)), L & 1));
+        const int sa = l == 0 || l == 3 ? W_TX : l == 2 ? W_TZ : l == 4 ? W_YZ : W_TY, sb = l == 3 ? W_TX : l == 2 ? W_TZ : l == 4 ? W_YZ : W_TY;
+        m.sth(W_G + l, L & 1, wide_half_mul(m.ld(sa), m.ld(sb), L & 1));
     });
-    // round 2: G5 = E = 3 C b',  c3 = 3 J xP,  c0 = -H yP with H = YZ - (B + C) (G6 = H normalised)
+    // linear: H = YY - (B + C), 3 C, 3 J
+    m.limbs(6, [&](auto &o, int c) {
+        const int w = c >> 1, h = c & 1;
+        const auto X = o.ld(w == 1 ? W_G + 2 : W_G + 3, h);
+        const auto vH = o.sub(o.ld(W_G + 4, h), o.add(o.ld(W_G + 1, h), o.ld(W_G + 2, h))), v3 = o.add(o.dbl(X), X);
+        o.st(w == 0 ? W_HN : w == 1 ? W_C3 : W_J3, h, o.norm(o.sel(w == 0, vH, v3)));
+    });
+    // round 2: G5 = E = 3 C b',  c3 = 3 J xP,  c0 = -H yP
     m.run(6, [&](int L) {
         const int l = L >> 1;
-        const F2 H = f2_sub(m.ld(W_G + 4), f2_add(m.ld(W_G + 1), m.ld(W_G + 2)));
-        const F2 v = m.ld(l == 0 ? W_G + 2 : W_G + 3);
-        const F2 lhs = f2_sel(l == 2, f2_norm(f2_neg(H)), f2_norm(f2_add(f2_dbl(v), v)));
+        const F2 v = m.ld(l == 0 ? W_C3 : l == 1 ? W_J3 : W_HN);
         const F2 rhs = f2_sel(l == 0, b_twist29(), m.ld(l == 1 ? W_XP : W_YP));
-        m.sth(l == 0 ? W_G + 5 : l == 1 ? W_L3 : W_L0, L & 1, wide_half_mul(lhs, rhs, L & 1));
-        if (l == 2) m.sth(W_G + 6, L & 1, fe_norm((L & 1) ? H.a1 : H.a0));
+        m.sth(l == 0 ? W_G + 5 : l == 1 ? W_L3 : W_L0, L & 1, wide_half_mul(f2_sel(l == 2, f2_neg(v), v), rhs, L & 1));
     });
-    // round 3: x' = A (B - F), G7 = G^2, G8 = E^2, z' = B H      (A = XY / 2, F = 3 E, G = (B + F) / 2)
+    // linear: A = XY / 2,  B - F,  G = (B + F) / 2      (F = 3 E)
+    m.limbs(6, [&](auto &o, int c) {
+        const int w = c >> 1, h = c & 1;
+        const auto B = o.ld(W_G + 1, h), E = o.ld(W_G + 5, h);
+        const auto F = o.add(o.dbl(E), E);
+        const auto halved = o.halve(o.sel(w == 0, o.ld(W_G, h), o.norm(o.add(B, F))));
+        o.st(w == 0 ? W_AH : w == 1 ? W_BF : W_GG, h, o.norm(o.sel(w == 1, o.sub(B, F), halved)));
+    });
+    // round 3: x' = A (B - F), G7 = G^2, G8 = E^2, z' = B H
     m.run(8, [&](int L) {
         const int l = L >> 1;
-        const F2 XY = m.ld(W_G), B = m.ld(W_G + 1), E = m.ld(W_G + 5), Hn = m.ld(W_G + 6);
-        const F2 F = f2_add(f2_dbl(E), E);
-        const F2 A = f2_halve(XY), G = f2_norm(f2_halve(f2_norm(f2_add(B, F))));
-        const F2 lhs = f2_sel(l == 0, f2_norm(A), f2_sel(l == 1, G, f2_sel(l == 2, E, B)));
-        const F2 rhs = f2_sel(l == 0, f2_norm(f2_sub(B, F)), f2_sel(l == 1, G, f2_sel(l == 2, E, Hn)));
+        const F2 lhs = m.ld(l == 0 ? W_AH : l == 1 ? W_GG : l == 2 ? W_G + 5 : W_G + 1), rhs = m.ld(l == 0 ? W_BF : l == 1 ? W_GG : l == 2 ? W_G + 5 : W_HN);
         m.sth(l == 0 ? W_TX : l == 1 ? W_G + 7 : l == 2 ? W_G + 8 : W_TZ, L & 1, wide_half_mul(lhs, rhs, L & 1));
     });
-    // linear: y' = G^2 - 3 E^2,  c4 = E - B
-    m.run(4, [&](int L) {
-        const int l = L >> 1, h = L & 1;
-        const Fe EE = m.ldh(W_G + 8, h);
-        const Fe y = fe_sub(m.ldh(W_G + 7, h), fe_add(fe_dbl(EE), EE)), c4 = fe_sub(m.ldh(W_G + 5, h), m.ldh(W_G + 1, h));
-        m.sth(l == 0 ? W_TY : W_L4, h, fe_norm(fe_sel(l == 0, y, c4)));
+    // linear: y' = G^2 - 3 E^2,  c4 = E - B,  and y' + z' for the next step
+    m.limbs(6, [&](auto &o, int c) {
+        const int w = c >> 1, h = c & 1;
+        const auto EE = o.ld(W_G + 8, h);
+        const auto y = o.norm(o.sub(o.ld(W_G + 7, h), o.add(o.dbl(EE), EE)));
+        const auto c4 = o.norm(o.sub(o.ld(W_G + 5, h), o.ld(W_G + 1, h)));
+        const auto yz = o.norm(o.add(y, o.ld(W_TZ, h)));
+        o.st(w == 0 ? W_TY : w == 1 ? W_L4 : W_YZ, h, o.sel(w == 0, y, o.sel(w == 1, c4, yz)));
     });
 }
 // T <- T + Q' and the chord (Q' = slots qx, qy); with_point = false: the chord alone (last step of the loop)
@@ -280,10 +318,10 @@ template <class M> GPBC_INLINE void wide_add_step(M &m, int qx, int qy, bool wit
         const int l = L >> 1;
         const F2 a = m.ld(l == 0 || l == 2 || l == 5 ? W_G : W_G + 1);
         const F2 b = m.ld(l == 0 ? W_G : l == 1 ? W_G + 1 : l == 2 ? qx : l == 3 ? qy : l == 4 ? W_YP : W_XP);
-        m.sth(l < 4 ? W_G + 2 + l : l == 4 ? W_L0 : W_L3, L & 1, wide_half_mul(f2_sel(l == 5, f2_norm(f2_neg(a)), a), b, L & 1));
+        m.sth(l < 4 ? W_G + 2 + l : l == 4 ? W_L0 : W_L3, L & 1, wide_half_mul(f2_sel(l == 5, f2_neg(a), a), b, L & 1));
     });
     if (!with_point) {
-        m.run(2, [&](int h) { m.sth(W_L4, h, fe_norm(fe_sub(m.ldh(W_G + 4, h), m.ldh(W_G + 5, h)))); });
+        m.limbs(2, [&](auto &o, int c) { o.st(W_L4, c, o.norm(o.sub(o.ld(W_G + 4, c), o.ld(W_G + 5, c)))); });
         return;
     }
     // round 3: G6 = E = L D, G7 = F = z C, G8 = G = x D
@@ -291,19 +329,27 @@ template <class M> GPBC_INLINE void wide_add_step(M &m, int qx, int qy, bool wit
         const int l = L >> 1;
         m.sth(W_G + 6 + l, L & 1, wide_half_mul(m.ld(l == 0 ? W_G + 1 : l == 1 ? W_TZ : W_TX), m.ld(l == 1 ? W_G + 2 : W_G + 3), L & 1));
     });
-    // round 4: G9 = x' = L H, G10 = U = (G - H) O, G11 = t1 = y E, G2 = z' = E z       (H = E + F - 2 G)
+    // linear: H = E + F - 2 G,  G - H
+    m.limbs(4, [&](auto &o, int c) {
+        const int w = c >> 1, h = c & 1;
+        const auto G = o.ld(W_G + 8, h);
+        const auto H = o.norm(o.sub(o.add(o.ld(W_G + 6, h), o.ld(W_G + 7, h)), o.dbl(G)));
+        o.st(w == 0 ? W_HH : W_GH, h, o.sel(w == 0, H, o.norm(o.sub(G, H))));
+    });
+    // round 4: x' = L H, G10 = U = (G - H) O, G11 = t1 = y E, z' = E z   (x' and z' go straight to T: every operand of the round is
+    // read before any lane stores)
     m.run(8, [&](int L) {
         const int l = L >> 1;
-        const F2 E = m.ld(W_G + 6), F = m.ld(W_G + 7), G = m.ld(W_G + 8);
-        const F2 H = f2_norm(f2_sub(f2_add(E, F), f2_dbl(G)));
-        const F2 a = m.ld(l == 0 ? W_G + 1 : l == 2 ? W_TY : W_G + 6), b = m.ld(l == 1 ? W_G : l == 2 ? W_G + 6 : W_TZ);
-        m.sth(l == 3 ? W_G + 2 : W_G + 9 + l, L & 1, wide_half_mul(f2_sel(l == 1, f2_norm(f2_sub(G, H)), a), f2_sel(l == 0, H, b), L & 1));
+        const F2 a = m.ld(l == 0 ? W_G + 1 : l == 1 ? W_GH : l == 2 ? W_TY : W_G + 6), b = m.ld(l == 0 ? W_HH : l == 1 ? W_G : l == 2 ? W_G + 6 : W_TZ);
+        m.sth(l == 0 ? W_TX : l == 1 ? W_G + 10 : l == 2 ? W_G + 11 : W_TZ, L & 1, wide_half_mul(a, b, L & 1));
     });
-    // linear: T <- (x', U - t1, z'),  c4 = M1 - M2
-    m.run(8, [&](int L) {
-        const int l = L >> 1, h = L & 1;
-        const Fe a = m.ldh(l == 0 ? W_G + 9 : l == 1 ? W_G + 10 : l == 2 ? W_G + 2 : W_G + 4, h), b = m.ldh(l == 1 ? W_G + 11 : W_G + 5, h);
-        m.sth(l == 0 ? W_TX : l == 1 ? W_TY : l == 2 ? W_TZ : W_L4, h, fe_sel(l == 1 || l == 3, fe_norm(fe_sub(a, b)), a));
+    // linear: y' = U - t1,  c4 = M1 - M2,  and y' + z' for the next step
+    m.limbs(6, [&](auto &o, int c) {
+        const int w = c >> 1, h = c & 1;
+        const auto y = o.norm(o.sub(o.ld(W_G + 10, h), o.ld(W_G + 11, h)));
+        const auto c4 = o.norm(o.sub(o.ld(W_G + 4, h), o.ld(W_G + 5, h)));
+        const auto yz = o.norm(o.add(y, o.ld(W_TZ, h)));
+        o.st(w == 0 ? W_TY : w == 1 ? W_L4 : W_YZ, h, o.sel(w == 0, y, o.sel(w == 1, c4, yz)));
     });
 }
 
@@ -313,7 +359,7 @@ template <class M> GPBC_INLINE void wide_add_step(M &m, int qx, int qy, bool wit
 //   emit(j): line j is in W_L0, W_L3, W_L4          fetch(j): put line j into W_CL .. W_CL + 2
 template <class M, class Emit> GPBC_INLINE void wide_miller_lines(M &m, const G1A &p, const G2A &q, Emit &&emit) {
     m.run(1, [&](int) {
-        m.st(W_TX, q.x); m.st(W_TY, q.y); m.st(W_TZ, f2_one());
+        m.st(W_TX, q.x); m.st(W_TY, q.y); m.st(W_TZ, f2_one()); m.st(W_YZ, f2_norm(f2_add(q.y, f2_one())));
         m.st(W_QX, q.x); m.st(W_QY, q.y); m.st(W_NQY, f2_neg(q.y));
         m.st(W_Q1X, f2_mul(f2_conj(q.x), gamma29(1, 2))); m.st(W_Q1Y, f2_mul(f2_conj(q.y), gamma29(1, 3)));
         m.st(W_Q2X, f2_mul(q.x, gamma29(2, 2))); m.st(W_Q2Y, f2_norm(f2_neg(f2_mul(q.y, gamma29(2, 3)))));
@@ -422,6 +468,7 @@ template <class M> GPBC_INLINE bool wide_is_cyclotomic(M &m, int a, int t2, int 
         const F2 d = f2_norm(f2_sub(m.ld(t4 + c), m.ld(t2 + c)));
         m.st(W_G + c, f2_sel(f2_is_zero(d), f2_one(), f2_zero()));
     });
+    m.sync_waves();                                          // a helper wave (it sat the phase out) must not read the flags before they are there: it takes the same branch
     bool ok = true;
     for (int c = 0; c < 6; c++) ok = ok && !f2_is_zero(m.ld(W_G + c));
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(GPBC_BOUNDS)

@@ -116,6 +116,10 @@ struct WideHost {
     Fe ldh(int i, int h) const { return h ? s[i].a1 : s[i].a0; }
     void st(int i, const F2 &v) { pending.emplace_back(i, v); }
     void sth(int i, int h, const Fe &v) { pending_half.emplace_back(i, h, v); }
+    int waves() const { return 2; }                        // the form with the helper wave (half products in wide_mul); the one-wave form multiplies whole F2 products: f2_mul, covered by the throughput kernels' runs
+    template <class B> void run2(int n, B &&body) { run(n, body); }
+    void sync_waves() const {}
+    template <class B> void limbs(int n_comp, B &&body) { LimbOpsFe<WideHost> o{*this}; run(n_comp, [&](int c) { body(o, c); }); }
     template <class B> void run(int n, B &&body) {
         for (int l = 0; l < n; l++) body(l);
         for (auto &p : pending) s[p.first] = p.second;

@@ -57,7 +57,9 @@ template <class M> struct LimbOpsFe {
     static V sub(const V &a, const V &b) { return fe_sub(a, b); }
     static V dbl(const V &a) { return fe_dbl(a); }
     static V neg(const V &a) { return fe_neg(a); }
-    static V sel(bool c, const V &a, const V &b) { return fe_sel(c, a, b); }
+    // a choice by COMPONENT NUMBER (which output this is): the host knows the component, so the bound is the chosen value's — fe_sel's
+    // "either lane" bound would price every output at the largest candidate.  (The device picks per lane; same values.)
+    static V sel(bool c, const V &a, const V &b) { return c ? a : b; }
     static V norm(const V &a) { return fe_norm(a); }
     static V halve(const V &a) { return fe_halve(a); }
 };
@@ -94,7 +96,8 @@ template <class M, class Term> GPBC_INLINE void wide_recombine(M &m, int dst, in
                     int slot;
                     bool wraps;
                     term(k, t, slot, wraps);
-                    const int32_t mine = m.ldw(slot, h, i), other = m.ldw(slot, 1 - h, i);
+                    const bool there = slot >= 0;                              // (a coefficient may have fewer terms than n_terms: slot -1)
+                    const int32_t mine = there ? m.ldw(there ? slot : 0, h, i) : 0, other = there ? m.ldw(there ? slot : 0, 1 - h, i) : 0;
                     lo += wraps ? 0 : mine; hi += wraps ? mine : 0; ho += wraps ? other : 0;
                     if (t % 3 == 2) { lo = norm(lo); hi = norm(hi); ho = norm(ho); }
                 }
@@ -115,7 +118,7 @@ template <class M, class Term> GPBC_INLINE void wide_recombine(M &m, int dst, in
             int slot;
             bool wraps;
             term(k, t, slot, wraps);
-            const Fe mine = m.ldh(slot, h), other = m.ldh(slot, 1 - h);
+            const Fe mine = slot >= 0 ? m.ldh(slot, h) : fe_zero(), other = slot >= 0 ? m.ldh(slot, 1 - h) : fe_zero();
             lo = fe_add(lo, fe_sel(wraps, fe_zero(), mine)); hi = fe_add(hi, fe_sel(wraps, mine, fe_zero())); ho = fe_add(ho, fe_sel(wraps, other, fe_zero()));
             if (t % 3 == 2) { lo = fe_norm(lo); hi = fe_norm(hi); ho = fe_norm(ho); }
         }
@@ -138,6 +141,31 @@ template <class M> GPBC_INLINE void wide_mul(M &m, int dst, int a, int b) {
         wraps = j < 0;
         if (wraps) j += 6;
         slot = W_PROD + i * 6 + j;
+    });
+}
+// dst = a^2 for any a.  Of the 36 products a_i a_j only the 21 with i <= j are distinct; those with i < j count twice.  21 products as 42
+// halves fit ONE wave (where the general product's 72 need the helper), each lane a 243-MAD leaf: half the product phase of wide_mul —
+// this is the accumulator's f <- f^2 of every Miller step.  A product with i < j is stored doubled and normalised by the lane that made
+// it (36 instructions beside a leaf of ~300), so the recombination is the general one over at most four terms per coefficient.
+template <class M> GPBC_INLINE void wide_sqr(M &m, int dst, int a) {
+    m.run(42, [&](int L) {
+        const int p = L >> 1;
+        // pair number p -> (i, j), i <= j, rows of 6, 5, 4, 3, 2, 1 pairs
+        const int i = p < 6 ? 0 : p < 11 ? 1 : p < 15 ? 2 : p < 18 ? 3 : p < 20 ? 4 : 5;
+        const int j = p - (i == 0 ? 0 : i == 1 ? 5 : i == 2 ? 9 : i == 3 ? 12 : i == 4 ? 14 : 15);
+        const Fe r = wide_half_mul(m.ld(a + w2t(i)), m.ld(a + w2t(j)), L & 1);
+        m.sth(W_PROD + p, L & 1, fe_sel(i < j, fe_norm(fe_dbl(r)), r));
+    });
+    wide_recombine(m, dst, 4, [](int k, int t, int &slot, bool &wraps) {
+        // the t-th pair (i <= j) with i + j = k or k + 6, in order of i, as its number among the 21 (+ 64 when it wraps, -1: none) —
+        // a table by (t, k) written as selections: k differs from lane to lane, t is the unrolled loop's constant
+        auto by_k = [&](int c0, int c1, int c2, int c3, int c4, int c5) { return k == 0 ? c0 : k == 1 ? c1 : k == 2 ? c2 : k == 3 ? c3 : k == 4 ? c4 : c5; };
+        const int code = t == 0 ? k                                                       // (0, k)
+                       : t == 1 ? by_k(64 + 10, 64 + 14, 6, 7, 8, 9)                       // (1,5)' (2,5)' (1,1) (1,2) (1,3) (1,4)
+                       : t == 2 ? by_k(64 + 13, 64 + 16, 64 + 17, 64 + 19, 11, 12)         // (2,4)' (3,4)' (3,5)' (4,5)' (2,2) (2,3)
+                                : by_k(64 + 15, -1, 64 + 18, -1, 64 + 20, -1);             // (3,3)' none (4,4)' none (5,5)' none
+        wraps = code >= 64;
+        slot = code < 0 ? -1 : W_PROD + (code & 63);
     });
 }
 // dst = a * (c0 + c3 w + c4 w^3): the line of a Miller step (three slots at `line`).  18 products as 36 halves, three terms per coefficient.
@@ -388,7 +416,7 @@ template <class M, class Fetch> GPBC_INLINE void wide_miller_accumulate(M &m, in
             // the first doubling: f = 1^2 * l = c0 + c3 w + c4 w^3
             m.run(6, [&](int k) { m.st(f + k, f2_sel(k == 0 || k == 3 || k == 4, m.ld(k == 0 ? W_CL : k == 3 ? W_CL + 1 : W_CL + 2), f2_zero())); });
         } else {
-            wide_mul(m, f, f, f);
+            wide_sqr(m, f, f);
             wide_mul_line(m, f, f, W_CL);
         }
         if (ate_naf_digit(i) != 0) {
@@ -487,7 +515,7 @@ template <class M> GPBC_INLINE void wide_exp256(M &m, const uint32_t (&k)[8]) {
         uint32_t d = k[word] >> sh;
         if (sh > 29 && word < 7) d |= k[word + 1] << (32 - sh);
         d &= 7u;
-        if (started) for (int q = 0; q < 3; q++) { if (cyclotomic) wide_cyclo_sqr(m, Z, Z); else wide_mul(m, Z, Z, Z); }
+        if (started) for (int q = 0; q < 3; q++) { if (cyclotomic) wide_cyclo_sqr(m, Z, Z); else wide_sqr(m, Z, Z); }
         if (d) {
             if (started) wide_mul(m, Z, Z, wv((int)d));
             else { wide_copy(m, Z, wv((int)d)); started = true; }

@@ -245,6 +245,12 @@ struct SmallCall {
 using SmallBatchFn = int (*)(CallLane &lane, SmallCall *const *calls, size_t n_calls);
 // Runs `c` through the combiner of the calling thread's current device; returns the call's status with gpbc_last_error() set.
 int small_call(SmallKind kind, SmallCall &c, SmallBatchFn run);
+// The same lanes for small calls that are NOT combined (wire formats, hash to curve, fixed-base sums: one call = one launch): the caller
+// takes a free lane (waits for one), stages through its pinned block, launches on its stream, waits for that stream alone — off the null
+// stream and without the device-wide synchronisation a DevBuf costs when it is freed, so such a call neither waits for the batches of
+// other threads nor makes them wait.  body runs on the calling thread with the lane's buffers reserved by itself (lane.reserve).
+int with_call_lane(const std::function<int(CallLane &)> &body);
+constexpr size_t LANE_CALL_MAX_UNITS = 16384;       // elements per such call (the quad-of-lanes kernels' range); larger calls keep the bulk path
 void free_call_lanes();
 
 #endif

@@ -35,6 +35,8 @@ struct DeviceCtx {
     CallLane lanes[CALL_LANES];
     std::deque<SmallCall *> waiting[CALL_KINDS];
     int next_kind = 0;                                   // where the search for the next leader starts (round robin over the kinds)
+    std::condition_variable lane_cv;                     // with_call_lane waiters
+    int lane_waiters = 0;
 };
 static DeviceCtx g_ctx[MAX_DEVICES];
 static std::atomic<int> g_ndev{0};
@@ -192,9 +194,45 @@ int small_call(SmallKind kind, SmallCall &c, SmallBatchFn run) {
             if (!x.waiting[k2].empty()) { x.waiting[k2].front()->cv.notify_one(); free_lanes--; }
         }
         x.next_kind = (x.next_kind + 1) % CALL_KINDS;
+        if (x.lane_waiters) x.lane_cv.notify_one();
     }
     if (c.rc != GPBC_OK) return fail(c.rc, "%s", c.err);
     return GPBC_OK;
+}
+int with_call_lane(const std::function<int(CallLane &)> &body) {
+    const int n = g_ndev.load(), di = cur_index();
+    if (n <= 0 || di >= n) return fail(GPBC_ERR_NO_DEVICE, "gpbc_init() has not bound a HIP device (no CPU fallback exists)");
+    TRY(bind_device());
+    DeviceCtx &x = g_ctx[di];
+    CallLane *lane = nullptr;
+    {
+        std::unique_lock<std::mutex> lk(x.calls_mu);
+        for (;;) {
+            for (auto &l : x.lanes) if (!l.busy) { lane = &l; break; }
+            if (lane) break;
+            x.lane_waiters++;
+            x.lane_cv.wait(lk);
+            x.lane_waiters--;
+        }
+        lane->busy = true;
+        lane->device = di;
+    }
+    int rc = GPBC_OK;
+    if (!lane->stream && hipStreamCreateWithFlags(&lane->stream, hipStreamNonBlocking) != hipSuccess) rc = fail(GPBC_ERR_HIP, "hipStreamCreateWithFlags failed for a call lane");
+    if (rc == GPBC_OK) rc = body(*lane);
+    if (lane->stream) (void)hipStreamSynchronize(lane->stream);      // (a no-op after a successful body, which has synchronised; after a failure nothing may still run)
+    {
+        std::lock_guard<std::mutex> lk(x.calls_mu);
+        lane->busy = false;
+        // the lane is free: a waiting combined request leads next, or another uncombined call takes it
+        bool woke = false;
+        for (int t = 0; t < CALL_KINDS && !woke; t++) {
+            const int k2 = (x.next_kind + t) % CALL_KINDS;
+            if (!x.waiting[k2].empty()) { x.waiting[k2].front()->cv.notify_one(); woke = true; }
+        }
+        if (x.lane_waiters) x.lane_cv.notify_one();
+    }
+    return rc;
 }
 void free_call_lanes() {
     int keep = -1;

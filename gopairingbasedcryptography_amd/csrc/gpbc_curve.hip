@@ -592,6 +592,16 @@ int gpbc_fixed_base_msm(const gpbc_fixed_base *h, const void *scalars, size_t n_
     if (!scalars || !out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
     TRY(bind_device());
     const size_t pt = h->is_g2 ? GPBC_G2_BYTES : GPBC_G1_BYTES;
+    if (n_msm * h->nbase <= LANE_CALL_MAX_UNITS)      // ScalarMultiplicationBase as the reference calls it (one scalar): through a call lane, gpbc_common.hpp
+        return with_call_lane([&](CallLane &l) {
+            const size_t sb = n_msm * h->nbase * GPBC_SCALAR_BYTES, o_out = Scratch::padded(sb), wsb = gpbc_fixed_base_msm_workspace_bytes(h, n_msm);
+            TRY(l.reserve(o_out + Scratch::padded(n_msm * pt), wsb));
+            memcpy(l.pin, scalars, sb);
+            TRY(gpbc_fixed_base_msm_dev(h, l.d_pin, n_msm, l.d_pin + o_out, l.dev, wsb, l.stream));
+            HIP_TRY(hipStreamSynchronize(l.stream));
+            memcpy(out, l.pin + o_out, n_msm * pt);
+            return (int)GPBC_OK;
+        });
     DevBuf dS, dO, dW;
     TRY(dS.upload(scalars, n_msm * h->nbase * GPBC_SCALAR_BYTES)); TRY(dO.alloc(n_msm * pt));
     const size_t wsb = gpbc_fixed_base_msm_workspace_bytes(h, n_msm);

@@ -245,6 +245,16 @@ static int unmarshal_dev(int kind, const void *d_in, size_t elem_bytes, size_t n
 }
 static int marshal_one(int kind, const void *in, size_t n, int compressed, void *out) {
     TRY(bind_device());
+    if (n <= LANE_CALL_MAX_UNITS)      // a small call: through a call lane (pinned block in and out, the lane's stream), gpbc_common.hpp
+        return with_call_lane([&](CallLane &l) {
+            const size_t ib = n * wire_mem_bytes(kind), ob = n * wire_enc_bytes(kind, compressed), o_out = Scratch::padded(ib);
+            TRY(l.reserve(o_out + Scratch::padded(ob), 0));
+            memcpy(l.pin, in, ib);
+            TRY(marshal_dev(kind, l.d_pin, n, compressed, l.d_pin + o_out, l.stream));
+            HIP_TRY(hipStreamSynchronize(l.stream));
+            memcpy(out, l.pin + o_out, ob);
+            return (int)GPBC_OK;
+        });
     DevBuf dI, dO;
     TRY(dI.upload(in, n * wire_mem_bytes(kind))); TRY(dO.alloc(n * wire_enc_bytes(kind, compressed)));
     TRY(marshal_dev(kind, dI.p, n, compressed, dO.p, nullptr));
@@ -262,6 +272,16 @@ static int marshal_host(int kind, const void *in, size_t n, int compressed, void
     });
 }
 static int unmarshal_one(int kind, const void *in, size_t elem_bytes, size_t n, void *out, uint8_t *ok) {
+    if (n && n <= LANE_CALL_MAX_UNITS)
+        return with_call_lane([&](CallLane &l) {
+            const size_t ib = n * elem_bytes, ob = n * wire_mem_bytes(kind), o_out = Scratch::padded(ib), o_ok = o_out + Scratch::padded(ob);
+            TRY(l.reserve(o_ok + Scratch::padded(n), 0));
+            memcpy(l.pin, in, ib);
+            TRY(unmarshal_dev(kind, l.d_pin, elem_bytes, n, l.d_pin + o_out, l.d_pin + o_ok, l.stream));
+            HIP_TRY(hipStreamSynchronize(l.stream));
+            memcpy(out, l.pin + o_out, ob); memcpy(ok, l.pin + o_ok, n);
+            return (int)GPBC_OK;
+        });
     DevBuf dI, dO, dK;
     if (n) {
         TRY(bind_device());
@@ -310,6 +330,16 @@ static int map_fields_dev(bool g2, const void *d_u, size_t n, void *d_out, void 
 static int map_fields_one(bool g2, const void *u, size_t n, void *out) {
     TRY(bind_device());
     size_t pt = g2 ? GPBC_G2_BYTES : GPBC_G1_BYTES;               // two field elements occupy as many bytes as one point
+    if (n <= LANE_CALL_MAX_UNITS)
+        return with_call_lane([&](CallLane &l) {
+            const size_t o_out = Scratch::padded(n * pt);
+            TRY(l.reserve(2 * o_out, 0));
+            memcpy(l.pin, u, n * pt);
+            TRY(map_fields_dev(g2, l.d_pin, n, l.d_pin + o_out, l.stream));
+            HIP_TRY(hipStreamSynchronize(l.stream));
+            memcpy(out, l.pin + o_out, n * pt);
+            return (int)GPBC_OK;
+        });
     DevBuf dU, dO;
     TRY(dU.upload(u, n * pt)); TRY(dO.alloc(n * pt));
     TRY(map_fields_dev(g2, dU.p, n, dO.p, nullptr));
@@ -360,6 +390,17 @@ static int hash_one(int what, const uint8_t *msgs, const uint64_t *off, size_t n
     const uint64_t base = off[0], bytes = off[n] - base;
     std::vector<uint64_t> rel(n + 1);
     for (size_t i = 0; i <= n; i++) rel[i] = off[i] - base;
+    if (n <= LANE_CALL_MAX_UNITS && bytes <= ((size_t)64 << 20))
+        return with_call_lane([&](CallLane &l) {
+            const size_t ob = n * hash_out_bytes(what), o_off = Scratch::padded(bytes), o_out = o_off + Scratch::padded((n + 1) * sizeof(uint64_t));
+            TRY(l.reserve(o_out + Scratch::padded(ob), 0));
+            if (bytes) memcpy(l.pin, msgs + base, bytes);
+            memcpy(l.pin + o_off, rel.data(), (n + 1) * sizeof(uint64_t));
+            TRY(hash_dev(what, l.d_pin, (const uint64_t *)(l.d_pin + o_off), bytes, n, dst, dst_len, l.d_pin + o_out, l.stream));
+            HIP_TRY(hipStreamSynchronize(l.stream));
+            memcpy(out, l.pin + o_out, ob);
+            return (int)GPBC_OK;
+        });
     DevBuf dM, dOff, dO;
     TRY(dM.upload(msgs + base, bytes)); TRY(dOff.upload(rel.data(), (n + 1) * sizeof(uint64_t))); TRY(dO.alloc(n * hash_out_bytes(what)));
     TRY(hash_dev(what, dM.p, (const uint64_t *)dOff.p, bytes, n, dst, dst_len, dO.p, nullptr));

@@ -4,6 +4,7 @@
 // results a lone caller gets.
 #include <cstdio>
 #include <cstring>
+#include <string>
 #include <thread>
 #include <vector>
 #include "gpbc_bn254.hpp"
@@ -63,11 +64,27 @@ int main() {
         wantExp[t].Exp(want[t][2], ks[t][3]);
         wantQ[t] = G2ScalarMultiplicationBatch({Q[t][4]}, {ks[t][5]})[0];
     }
+    // ... and the calls that are not combined but take a call lane each: ScalarMultiplicationBase (generator tables), HashToG2, Marshal /
+    // Unmarshal of one point — sequential references first
+    std::vector<G1Affine> wantBase(T);
+    std::vector<G2Affine> wantHash(T);
+    std::vector<std::vector<uint8_t>> wantWire(T);
+    for (int t = 0; t < T; t++) {
+        wantBase[t].ScalarMultiplicationBase(ks[t][6]);
+        wantHash[t] = HashToG2("message of thread class " + std::to_string(t), "Hash String To Element In G2");
+        wantWire[t] = Q[t][7].Marshal();
+    }
     for (int u = 0; u < T2; u++)
         th2.emplace_back([&, u] {
             const int t = u % T;
             for (int rep = 0; rep < REPS; rep++) {
                 const int i = (u * 7 + rep * 13) % N;
+                G1Affine bs; bs.ScalarMultiplicationBase(ks[t][6]);
+                if (!bs.Equal(wantBase[t])) bad2[u]++;
+                if (!HashToG2("message of thread class " + std::to_string(t), "Hash String To Element In G2").Equal(wantHash[t])) bad2[u]++;
+                const std::vector<uint8_t> wire = Q[t][7].Marshal();
+                G2Affine back; back.Unmarshal(wire);
+                if (wire != wantWire[t] || !back.Equal(Q[t][7])) bad2[u]++;
                 GT e = Pair({P[t][i]}, {Q[t][i]});
                 if (!e.Equal(want[t][i])) bad2[u]++;
                 G1Affine neg; neg.Neg(P[t][i]);

@@ -219,7 +219,7 @@ void free_workspaces();
 // touches the null stream, the device-wide scratch lock or hipDeviceSynchronize.
 constexpr int CALL_LANES = 4;
 constexpr size_t SMALL_CALL_MAX_UNITS = 2048;       // per batch (and per call): one round of wavefronts on the chip
-enum SmallKind { CALL_PAIRS = 0, CALL_G1_MUL, CALL_G2_MUL, CALL_GT_EXP, CALL_GT_MUL, CALL_GT_DIV, CALL_GT_INV, CALL_KINDS };
+enum SmallKind { CALL_PAIRS = 0, CALL_G1_MUL, CALL_G2_MUL, CALL_GT_EXP, CALL_GT_MUL, CALL_GT_DIV, CALL_GT_INV, CALL_HASH_G1, CALL_HASH_G2, CALL_FIXED_BASE, CALL_KINDS };
 struct CallLane {
     int device = -1;                 // index into the bound device list
     hipStream_t stream = nullptr;
@@ -236,7 +236,11 @@ struct SmallCall {
     void *out[2] = {nullptr, nullptr};
     size_t units = 0;                                  // pairs / points / GT elements
     const uint64_t *seg = nullptr;                     // CALL_PAIRS: the call's own segment table (segs + 1 entries); null = one pair per segment
-    size_t segs = 0;
+    size_t segs = 0;                                   //   (CALL_HASH_*: seg = the call's message offsets, units + 1 entries)
+    // Calls of one kind share a launch only if their keys are equal byte for byte: the domain-separation tag of a hash (a kernel
+    // argument), the table handle of a fixed-base sum.  No key: every call of the kind combines.
+    const void *key = nullptr;
+    size_t key_len = 0;
     int rc = GPBC_OK;
     char err[512] = "";
     bool taken = false, done = false;

@@ -166,11 +166,16 @@ int small_call(SmallKind kind, SmallCall &c, SmallBatchFn run) {
         auto &q = x.waiting[kind];
         batch.clear();
         size_t units = 0;
-        while (!q.empty() && (batch.empty() || units + q.front()->units <= SMALL_CALL_MAX_UNITS)) {
-            units += q.front()->units;
-            q.front()->taken = true;
-            batch.push_back(q.front());
-            q.pop_front();
+        // (the oldest request sets the batch's key; requests with another key stay queued, in order, for the next leader)
+        const SmallCall *head = q.front();
+        for (auto it = q.begin(); it != q.end();) {
+            SmallCall *r = *it;
+            const bool same = r->key_len == head->key_len && (r->key_len == 0 || memcmp(r->key, head->key, r->key_len) == 0);
+            if (!same || (!batch.empty() && units + r->units > SMALL_CALL_MAX_UNITS)) { ++it; continue; }
+            units += r->units;
+            r->taken = true;
+            batch.push_back(r);
+            it = q.erase(it);
         }
         lane->busy = true;
         lane->device = di;

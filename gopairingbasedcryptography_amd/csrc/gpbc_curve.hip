@@ -586,13 +586,36 @@ int gpbc_fixed_base_msm_dev(const gpbc_fixed_base *h, const void *d_scalars, siz
     }
     return GPBC_OK;
 }
+// Small fixed-base sums (ScalarMultiplicationBase as the reference calls it: one scalar against the generator table,
+// cpabe/bsw07/bsw07_cpabe.go:69, signature/bls01_signature/bls_signature.go:45) COMBINED per table: key = the handle, in[0] = the
+// call's scalars (segs rows of nbase each), in[1] = the handle, units = scalars (the batch cap counts terms).
+static int small_fixed_base_run(CallLane &lane, SmallCall *const *calls, size_t nc) {
+    const gpbc_fixed_base *h = (const gpbc_fixed_base *)calls[0]->in[1];
+    const size_t pt = h->is_g2 ? GPBC_G2_BYTES : GPBC_G1_BYTES, row = h->nbase * GPBC_SCALAR_BYTES;
+    size_t M = 0;
+    for (size_t c = 0; c < nc; c++) M += calls[c]->segs;
+    const size_t o_out = Scratch::padded(M * row), wsb = gpbc_fixed_base_msm_workspace_bytes(h, M);
+    TRY(lane.reserve(o_out + Scratch::padded(M * pt), wsb));
+    size_t m0 = 0;
+    for (size_t c = 0; c < nc; c++) { memcpy(lane.pin + m0 * row, calls[c]->in[0], calls[c]->segs * row); m0 += calls[c]->segs; }
+    TRY(gpbc_fixed_base_msm_dev(h, lane.d_pin, M, lane.d_pin + o_out, lane.dev, wsb, lane.stream));
+    HIP_TRY(hipStreamSynchronize(lane.stream));
+    m0 = 0;
+    for (size_t c = 0; c < nc; c++) { memcpy(calls[c]->out[0], lane.pin + o_out + m0 * pt, calls[c]->segs * pt); m0 += calls[c]->segs; }
+    return GPBC_OK;
+}
 int gpbc_fixed_base_msm(const gpbc_fixed_base *h, const void *scalars, size_t n_msm, void *out) {
     if (!h) return fail(GPBC_ERR_INVALID_ARG, "null table handle");
     if (!n_msm) return GPBC_OK;
     if (!scalars || !out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
     TRY(bind_device());
     const size_t pt = h->is_g2 ? GPBC_G2_BYTES : GPBC_G1_BYTES;
-    if (n_msm * h->nbase <= LANE_CALL_MAX_UNITS)      // ScalarMultiplicationBase as the reference calls it (one scalar): through a call lane, gpbc_common.hpp
+    if (n_msm * h->nbase <= SMALL_CALL_MAX_UNITS) {
+        SmallCall c;
+        c.in[0] = scalars; c.in[1] = h; c.out[0] = out; c.units = n_msm * h->nbase; c.segs = n_msm; c.key = &h; c.key_len = sizeof h;
+        return small_call(CALL_FIXED_BASE, c, small_fixed_base_run);
+    }
+    if (n_msm * h->nbase <= LANE_CALL_MAX_UNITS)      // larger, still small: one launch on a call lane of its own, gpbc_common.hpp
         return with_call_lane([&](CallLane &l) {
             const size_t sb = n_msm * h->nbase * GPBC_SCALAR_BYTES, o_out = Scratch::padded(sb), wsb = gpbc_fixed_base_msm_workspace_bytes(h, n_msm);
             TRY(l.reserve(o_out + Scratch::padded(n_msm * pt), wsb));

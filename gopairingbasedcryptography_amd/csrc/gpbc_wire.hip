@@ -385,11 +385,42 @@ static int hash_dev(int what, const void *d_msgs, const uint64_t *d_off, size_t 
     }
     return check_launch("k_hash");
 }
+// Small calls of HashToG1 / HashToG2 (every BLS Sign and Verify starts with one: signature/bls01_signature/bls_signature.go:58-63,75-79) are
+// COMBINED like the pairings (gpbc_common.hpp "Small host-pointer calls"): requests with the same domain-separation tag — the key —
+// share one launch; in[0] = the call's message bytes, seg = its offsets (rebased to 0), units = messages.
+static int small_hash_run(int what, CallLane &lane, SmallCall *const *calls, size_t nc) {
+    size_t N = 0, B = 0;
+    for (size_t c = 0; c < nc; c++) { N += calls[c]->units; B += (size_t)calls[c]->seg[calls[c]->units]; }
+    const size_t ob = hash_out_bytes(what), o_off = Scratch::padded(B), o_out = o_off + Scratch::padded((N + 1) * sizeof(uint64_t));
+    TRY(lane.reserve(o_out + Scratch::padded(N * ob), 0));
+    uint64_t *off = (uint64_t *)(lane.pin + o_off);
+    size_t n0 = 0, b0 = 0;
+    for (size_t c = 0; c < nc; c++) {
+        const SmallCall &r = *calls[c];
+        const size_t bytes = (size_t)r.seg[r.units];
+        if (bytes) memcpy(lane.pin + b0, r.in[0], bytes);
+        for (size_t i = 0; i < r.units; i++) off[n0 + i] = b0 + r.seg[i];
+        n0 += r.units; b0 += bytes;
+    }
+    off[N] = B;
+    TRY(hash_dev(what, lane.d_pin, (const uint64_t *)(lane.d_pin + o_off), B, N, calls[0]->key, calls[0]->key_len, lane.d_pin + o_out, lane.stream));
+    HIP_TRY(hipStreamSynchronize(lane.stream));
+    n0 = 0;
+    for (size_t c = 0; c < nc; c++) { memcpy(calls[c]->out[0], lane.pin + o_out + n0 * ob, calls[c]->units * ob); n0 += calls[c]->units; }
+    return GPBC_OK;
+}
+static int small_hash_g1_run(CallLane &l, SmallCall *const *c, size_t n) { return small_hash_run(0, l, c, n); }
+static int small_hash_g2_run(CallLane &l, SmallCall *const *c, size_t n) { return small_hash_run(1, l, c, n); }
 static int hash_one(int what, const uint8_t *msgs, const uint64_t *off, size_t n, const void *dst, size_t dst_len, uint8_t *out) {
     TRY(bind_device());
     const uint64_t base = off[0], bytes = off[n] - base;
     std::vector<uint64_t> rel(n + 1);
     for (size_t i = 0; i <= n; i++) rel[i] = off[i] - base;
+    if ((what == 0 || what == 1) && n <= SMALL_CALL_MAX_UNITS && bytes <= ((size_t)1 << 20) && dst_len <= 255) {
+        SmallCall c;
+        c.in[0] = msgs + base; c.seg = rel.data(); c.units = n; c.out[0] = out; c.key = dst; c.key_len = dst_len;
+        return what == 0 ? small_call(CALL_HASH_G1, c, small_hash_g1_run) : small_call(CALL_HASH_G2, c, small_hash_g2_run);
+    }
     if (n <= LANE_CALL_MAX_UNITS && bytes <= ((size_t)64 << 20))
         return with_call_lane([&](CallLane &l) {
             const size_t ob = n * hash_out_bytes(what), o_off = Scratch::padded(bytes), o_out = o_off + Scratch::padded((n + 1) * sizeof(uint64_t));

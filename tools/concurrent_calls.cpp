@@ -117,22 +117,47 @@ int main(int argc, char **argv) {
         if (gpbc_g1_scalar_mul_batch(&p.P[i * GPBC_G1_BYTES], 1, &p.k[i * GPBC_SCALAR_BYTES], 1, out) < 0) return false;
         return memcmp(out, &p.sP[i * GPBC_G1_BYTES], GPBC_G1_BYTES) == 0;
     };
-    for (int w = 0; w < 8; w++) { pair1(0, w); check2(0, w); g1mul1(0, w); }            // lanes, streams, code objects
+    // HashToG2 of one 32-byte message (every BLS Sign / Verify starts with it) and ScalarMultiplicationBase over the generator table
+    const char DST[] = "Hash Bytes To Element In G2";
+    std::vector<uint8_t> msgs(M * 32), hashed(M * GPBC_G2_BYTES), based(M * GPBC_G1_BYTES);
+    std::vector<uint64_t> offs(M + 1);
+    for (int i = 0; i < M; i++) { for (int w = 0; w < 4; w++) { uint64_t x = next(); memcpy(&msgs[i * 32 + 8 * w], &x, 8); } offs[i] = 32 * (uint64_t)i; }
+    offs[M] = 32 * (uint64_t)M;
+    OK(gpbc_hash_to_g2(msgs.data(), offs.data(), M, DST, sizeof DST - 1, hashed.data()));
+    gpbc_fixed_base *gen = nullptr;
+    OK(gpbc_g1_fixed_base_create(G1, 1, &gen));
+    OK(gpbc_fixed_base_msm(gen, p.k.data(), M, based.data()));
+    auto hash1 = [&](int u, long j) {
+        const int i = (int)((u * 37 + j) % M);
+        const uint64_t off[2] = {0, 32};
+        uint8_t out[GPBC_G2_BYTES];
+        if (gpbc_hash_to_g2(&msgs[i * 32], off, 1, DST, sizeof DST - 1, out) < 0) return false;
+        return memcmp(out, &hashed[i * GPBC_G2_BYTES], GPBC_G2_BYTES) == 0;
+    };
+    auto base1 = [&](int u, long j) {
+        const int i = (int)((u * 37 + j) % M);
+        uint8_t out[GPBC_G1_BYTES];
+        if (gpbc_fixed_base_msm(gen, &p.k[i * GPBC_SCALAR_BYTES], 1, out) < 0) return false;
+        return memcmp(out, &based[i * GPBC_G1_BYTES], GPBC_G1_BYTES) == 0;
+    };
+    for (int w = 0; w < 8; w++) { pair1(0, w); check2(0, w); g1mul1(0, w); hash1(0, w); base1(0, w); }            // lanes, streams, code objects
 
     printf("{\"what\": \"T OS threads looping one-element host-pointer calls for %.2f s per point; every result compared with a batched call's bytes\", \"seconds_per_point\": %.3f", seconds, seconds);
     long total_bad = 0;
-    const char *names[3] = {"pair_batch_1", "pairing_check_2_pairs", "g1_scalar_mul_1"};
-    for (int op = 0; op < 3; op++) {
+    const char *names[5] = {"pair_batch_1", "pairing_check_2_pairs", "g1_scalar_mul_1", "hash_to_g2_1", "g1_scalar_mul_base_1"};
+    for (int op = 0; op < 5; op++) {
         printf(", \"%s\": {", names[op]);
         for (size_t t = 0; t < threads.size(); t++) {
             const int T = threads[t];
-            Point r = op == 0 ? run_point(T, seconds, pair1) : op == 1 ? run_point(T, seconds, check2) : run_point(T, seconds, g1mul1);
+            Point r = op == 0 ? run_point(T, seconds, pair1) : op == 1 ? run_point(T, seconds, check2) : op == 2 ? run_point(T, seconds, g1mul1)
+                    : op == 3 ? run_point(T, seconds, hash1) : run_point(T, seconds, base1);
             total_bad += r.mismatches;
             printf("%s\"%d\": {\"calls_per_s\": %.1f, \"mean_ms_per_call\": %.4f, \"calls\": %ld, \"mismatches\": %ld}", t ? ", " : "", T, r.calls_per_s, r.mean_ms, r.calls, r.mismatches);
         }
         printf("}");
     }
     printf(", \"mismatches\": %ld}\n", total_bad);
+    gpbc_fixed_base_destroy(gen);
     gpbc_shutdown();
     return total_bad ? 1 : 0;
 }

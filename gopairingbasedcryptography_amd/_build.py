@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgpbc_bn254.so")
 STAMP = os.path.join(HERE, "libgpbc_bn254.buildhash")
 SOURCES = ["gpbc_core.hip", "gpbc_pairing.hip", "gpbc_curve.hip", "gpbc_wire.hip", "gpbc_msm.hip"]
-HEADERS = ["gpbc_common.hpp", "fe29.hip.hpp", "tower29.hip.hpp", "tower29_pair.hip.hpp", "curve29.hip.hpp", "pairing29.hip.hpp", "pairing29_pair.hip.hpp", "wide29.hip.hpp", "curve29_quad.hip.hpp",
+HEADERS = ["gpbc_common.hpp", "fe29.hip.hpp", "tower29.hip.hpp", "tower29_pair.hip.hpp", "curve29.hip.hpp", "pairing29.hip.hpp", "pairing29_pair.hip.hpp", "wide29.hip.hpp", "curve29_quad.hip.hpp", "curve29_oct.hip.hpp",
            "wire29.hip.hpp", "h2c29.hip.hpp", "xmd29.hip.hpp", "msm29.hip.hpp", "bn254_constants.hip.hpp", "bn254_constants29.hip.hpp"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC"]
 # host-only measurement program over the C ABI (bench.py runs it: calls/s of concurrent one-element calls); built next to the library

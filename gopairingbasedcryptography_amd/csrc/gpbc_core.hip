@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <deque>
 #include <dlfcn.h>
+#include <exception>
 #include <rccl/rccl.h>      // types and enums only: the library is opened with dlopen when a communicator is first asked for
 #include <string>
 #include <thread>
@@ -135,7 +136,9 @@ int CallLane::reserve(size_t pin_need, size_t dev_need) {
         while (want < pin_need) want <<= 1;
         if (pin) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipHostFree(pin)); pin = d_pin = nullptr; pin_bytes = 0; }
         void *h = nullptr, *d = nullptr;
-        HIP_TRY(hipHostMalloc(&h, want, hipHostMallocMapped));
+        // mapped into the device AND coherent, said explicitly: kernels write results here and the host reads them right after the stream
+        // synchronisation (the default follows an environment variable)
+        HIP_TRY(hipHostMalloc(&h, want, hipHostMallocMapped | hipHostMallocCoherent));
         if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipHostFree(h); return fail(GPBC_ERR_HIP, "hipHostGetDevicePointer failed for a call lane's pinned block"); }
         pin = (uint8_t *)h; d_pin = (uint8_t *)d; pin_bytes = want;
     }
@@ -182,7 +185,10 @@ int small_call(SmallKind kind, SmallCall &c, SmallBatchFn run) {
         lk.unlock();
         int rc = GPBC_OK;
         if (!lane->stream && hipStreamCreateWithFlags(&lane->stream, hipStreamNonBlocking) != hipSuccess) rc = fail(GPBC_ERR_HIP, "hipStreamCreateWithFlags failed for a call lane");
-        if (rc == GPBC_OK) rc = run(*lane, batch.data(), batch.size());
+        if (rc == GPBC_OK) {
+            try { rc = run(*lane, batch.data(), batch.size()); }
+            catch (const std::exception &e) { rc = fail(GPBC_ERR_INTERNAL, "small-call batch: %s", e.what()); }      // (allocation failure of a host table: no exception may cross the C ABI)
+        }
         if (rc != GPBC_OK && lane->stream) (void)hipStreamSynchronize(lane->stream);      // nothing of a failed batch may still be running when the lane is reused
         lk.lock();
         lane->busy = false;
@@ -224,7 +230,10 @@ int with_call_lane(const std::function<int(CallLane &)> &body) {
     }
     int rc = GPBC_OK;
     if (!lane->stream && hipStreamCreateWithFlags(&lane->stream, hipStreamNonBlocking) != hipSuccess) rc = fail(GPBC_ERR_HIP, "hipStreamCreateWithFlags failed for a call lane");
-    if (rc == GPBC_OK) rc = body(*lane);
+    if (rc == GPBC_OK) {
+        try { rc = body(*lane); }
+        catch (const std::exception &e) { rc = fail(GPBC_ERR_INTERNAL, "small call: %s", e.what()); }
+    }
     if (lane->stream) (void)hipStreamSynchronize(lane->stream);      // (a no-op after a successful body, which has synchronised; after a failure nothing may still run)
     {
         std::lock_guard<std::mutex> lk(x.calls_mu);

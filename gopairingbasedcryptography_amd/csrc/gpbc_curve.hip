@@ -1,7 +1,7 @@
 // libgpbc_bn254.so, unit 3 of 4: G1 / G2 scalar multiplication, point sums, fixed-base window tables and the sums over
 // them, with their C-ABI entries (include/gpbc_bn254.h).  gfx950 only.
 #include "gpbc_common.hpp"
-#include "curve29_quad.hip.hpp"
+#include "curve29_oct.hip.hpp"
 
 // Scalar multiplication: a lane owns SMUL_K points (t, t+T, t+2T, ...; T = ceil(n / SMUL_K)) whose Jacobian results share
 // one field inversion.  Measured on MI355X (2^20 points): K = 1 -> 36.9 M G1 / 15.0 M G2 per second, K = 2 -> 36.9 / 13.7,
@@ -74,6 +74,22 @@ GPBC_KERNEL k_g2_scalar_mul_quad(const uint8_t *__restrict__ bases, int shared_b
     load_scalar(k, scalars + i * GPBC_SCALAR_BYTES);
     JacP<F2> res;
     scalar_mul29_gls_quad(res, b, k, tabws + i * (size_t)glv_table_dwords<F2>(), q);
+    AffP<F2> aff;
+    jac_to_affine(aff, res);
+    if (q == 0) g2_store_aff(out + i * GPBC_G2_BYTES, aff);
+}
+
+// ... and G2 calls of a few points: one point per OCTET of lanes, the two halves of every Fp2 product on two lanes (csrc/curve29_oct.hip.hpp)
+constexpr size_t SMUL_OCT_MAX = 2048;
+GPBC_KERNEL k_g2_scalar_mul_oct(const uint8_t *__restrict__ bases, int shared_base, const uint8_t *__restrict__ scalars, uint8_t *__restrict__ out, size_t n, int32_t *__restrict__ tabws) {
+    const size_t lane = (size_t)blockIdx.x * BLOCK + threadIdx.x, i = lane >> 3;
+    const int q = (int)(lane & 7);
+    if (i >= n) return;
+    AffP<F2> b = g2_load_aff(bases + (shared_base ? 0 : i * GPBC_G2_BYTES));
+    uint32_t k[8];
+    load_scalar(k, scalars + i * GPBC_SCALAR_BYTES);
+    JacP<F2> res;
+    scalar_mul29_gls_oct(res, b, k, tabws + i * (size_t)glv_table_dwords<F2>(), q);
     AffP<F2> aff;
     jac_to_affine(aff, res);
     if (q == 0) g2_store_aff(out + i * GPBC_G2_BYTES, aff);
@@ -237,6 +253,12 @@ static int scalar_mul_dev(bool g2, const void *d_bases, size_t nbase, const void
         const size_t m = n - off < chunk ? n - off : chunk;
         const uint8_t *b = (const uint8_t *)d_bases + (shared ? 0 : off * pt), *k = (const uint8_t *)d_scalars + off * GPBC_SCALAR_BYTES;
         uint8_t *o = (uint8_t *)d_out + off * pt;
+        if (g2 && n <= SMUL_OCT_MAX) {
+            k_g2_scalar_mul_oct<<<grid_for(8 * m), BLOCK, 0, st>>>(b, shared, k, o, m, tabws);
+            TRY(check_launch("k_g2_scalar_mul_oct"));
+            profile_mark("k_g2_scalar_mul_oct", st);
+            continue;
+        }
         if (n <= SMUL_QUAD_MAX) {
             if (g2) k_g2_scalar_mul_quad<<<grid_for(4 * m), BLOCK, 0, st>>>(b, shared, k, o, m, tabws);
             else k_g1_scalar_mul_quad<<<grid_for(4 * m), BLOCK, 0, st>>>(b, shared, k, o, m, tabws);
@@ -304,7 +326,7 @@ static int small_mul_run(bool G2, CallLane &lane, SmallCall *const *calls, size_
         memcpy(lane.pin + oS + n0 * GPBC_SCALAR_BYTES, r.in[1], r.units * GPBC_SCALAR_BYTES);
         n0 += r.units;
     }
-    if (G2) k_g2_scalar_mul_quad<<<grid_for(4 * N), BLOCK, 0, lane.stream>>>(lane.d_pin + oB, 0, lane.d_pin + oS, lane.d_pin + oO, N, (int32_t *)lane.dev);
+    if (G2) k_g2_scalar_mul_oct<<<grid_for(8 * N), BLOCK, 0, lane.stream>>>(lane.d_pin + oB, 0, lane.d_pin + oS, lane.d_pin + oO, N, (int32_t *)lane.dev);   // N <= 2 048 = SMUL_OCT_MAX
     else k_g1_scalar_mul_quad<<<grid_for(4 * N), BLOCK, 0, lane.stream>>>(lane.d_pin + oB, 0, lane.d_pin + oS, lane.d_pin + oO, N, (int32_t *)lane.dev);
     TRY(check_launch(G2 ? "k_g2_scalar_mul_quad" : "k_g1_scalar_mul_quad"));
     profile_mark(G2 ? "k_g2_scalar_mul_quad" : "k_g1_scalar_mul_quad", lane.stream);

@@ -1,7 +1,7 @@
 // libgpbc_bn254.so, unit 4 of 5: gnark wire formats (csrc/wire29.hip.hpp) and hash to curve — hash_to_field
 // (csrc/xmd29.hip.hpp) and the group part (csrc/h2c29.hip.hpp) — with their C-ABI entries (include/gpbc_bn254.h).  gfx950 only.
 #include "gpbc_common.hpp"
-#include "curve29_quad.hip.hpp"
+#include "curve29_oct.hip.hpp"
 #include "wire29.hip.hpp"
 #include "h2c29.hip.hpp"
 #include "xmd29.hip.hpp"
@@ -61,6 +61,36 @@ GPBC_KERNEL k_g2_decode_quad(const uint8_t *__restrict__ in, int elem_bytes, uin
     const int q = (int)(lane & 3);
     const bool good = g2_wire_decode(out + i * GPBC_G2_BYTES, in + i * (size_t)elem_bytes, elem_bytes, [&](const F2 &x, const F2 &y) { return g2_in_subgroup29_quad(x, y, q); });
     if (q == 0) ok[i] = good ? 1 : 0;                            // (the four lanes wrote the same point bytes)
+}
+// ... and with one element per OCTET (calls of up to WIRE_OCT_MAX elements: one Unmarshal): the same chain with the two halves of every
+// Fp2 product on two lanes (csrc/curve29_oct.hip.hpp)
+constexpr size_t WIRE_OCT_MAX = 2048;
+__device__ __forceinline__ bool g2_in_subgroup29_oct(const F2 &x, const F2 &y, int q) {
+    constexpr uint64_t X = 4965661367192848881ull;
+    AffP<F2> pt{x, y, false};
+    JacP<F2> xq;
+    jac_set_inf(xq);
+    for (int i = 62; i >= 0; i--) {
+        jac_dbl_oct(xq, q);
+        if ((X >> i) & 1) jac_add_mixed_oct(xq, pt, q);
+    }
+    JacP<F2> lhs = xq, t, rhs;
+    jac_add_mixed_oct(lhs, pt, q);                               // [x+1]Q
+    jac_add(lhs, lhs, jac_psi_tw(xq, 1));
+    jac_add(lhs, lhs, jac_psi_tw(xq, 2));
+    t = xq;
+    jac_dbl_oct(t, q);
+    rhs = jac_psi_tw(t, 3);
+    if (!rhs.inf) rhs.y = f2_neg(rhs.y);
+    jac_add(t, lhs, rhs);                                        // lhs - rhs
+    return t.inf;
+}
+GPBC_KERNEL k_g2_decode_oct(const uint8_t *__restrict__ in, int elem_bytes, uint8_t *__restrict__ out, uint8_t *__restrict__ ok, size_t n) {
+    const size_t lane = (size_t)blockIdx.x * BLOCK + threadIdx.x, i = lane >> 3;
+    if (i >= n) return;
+    const int q = (int)(lane & 7);
+    const bool good = g2_wire_decode(out + i * GPBC_G2_BYTES, in + i * (size_t)elem_bytes, elem_bytes, [&](const F2 &x, const F2 &y) { return g2_in_subgroup29_oct(x, y, q); });
+    if (q == 0) ok[i] = good ? 1 : 0;
 }
 GPBC_KERNEL k_gt_decode(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, uint8_t *__restrict__ ok, size_t n) {
     size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -170,6 +200,53 @@ __device__ __forceinline__ void g2_map_fields_quad(AffP<F2> &out, const F2 &u0, 
     g2_clear_cofactor29_quad(c, a, q);
     jac_to_affine(out, c);
 }
+// ... and G2 with one message per OCTET (calls of up to H2C_OCT_MAX messages: the HashToG2 of one Sign or Verify): lanes q & 1 map u0 / u1,
+// the [x]P chain of the cofactor clearing runs on half products (csrc/curve29_oct.hip.hpp)
+constexpr size_t H2C_OCT_MAX = 2048;
+__device__ __forceinline__ void g2_clear_cofactor29_oct(JacP<F2> &out, const AffP<F2> &p, int q) {
+    constexpr uint64_t X = 4965661367192848881ull;
+    JacP<F2> xq, t;
+    jac_set_inf(xq);
+    for (int i = 62; i >= 0; i--) {
+        jac_dbl_oct(xq, q);
+        if ((X >> i) & 1) jac_add_mixed_oct(xq, p, q);
+    }
+    t = xq;
+    jac_dbl_oct(t, q);
+    jac_add(t, t, xq);                                          // [3x]P
+    JacP<F2> pj{p.x, p.y, f2_one(), p.inf};
+    JacP<F2> acc;
+    jac_add(acc, xq, jac_psi(t, 1));
+    jac_add(acc, acc, jac_psi(xq, 2));
+    jac_add(out, acc, jac_psi(pj, 3));
+}
+__device__ __forceinline__ void g2_map_fields_oct(AffP<F2> &out, const F2 &u0, const F2 &u1, int q) {
+    AffP<F2> q0, q1, a;
+    map_pair_quad<F2>(q0, q1, u0, u1, q & 3);                   // (each quad of the octet maps both: lanes 0 / 1 and 4 / 5)
+    JacP<F2> s{q0.x, q0.y, f2_one(), false}, c;
+    jac_add_mixed_oct(s, q1, q);
+    jac_to_affine(a, s);
+    g2_clear_cofactor29_oct(c, a, q);
+    jac_to_affine(out, c);
+}
+GPBC_KERNEL k_g2_map_fields_oct(const uint8_t *__restrict__ u, uint8_t *__restrict__ out, size_t n) {
+    const size_t lane = (size_t)blockIdx.x * BLOCK + threadIdx.x, i = lane >> 3;
+    if (i >= n) return;
+    AffP<F2> r;
+    g2_map_fields_oct(r, f2_load(u + i * 128), f2_load(u + i * 128 + 64), (int)(lane & 7));
+    if ((lane & 7) == 0) g2_store_aff(out + i * GPBC_G2_BYTES, r);
+}
+GPBC_KERNEL k_g2_hash_oct(const uint8_t *__restrict__ msgs, const uint64_t *__restrict__ off, size_t total, size_t n, XmdDst dst, uint8_t *__restrict__ out) {
+    const size_t lane = (size_t)blockIdx.x * BLOCK + threadIdx.x, i = lane >> 3;
+    if (i >= n) return;
+    uint64_t lo, len;
+    msg_range(off, total, i, lo, len);
+    uint32_t u[48];
+    expand_message_xmd<6>(u, msgs + lo, len, dst);
+    AffP<F2> r;
+    g2_map_fields_oct(r, F2{xmd_field(u, 0), xmd_field(u, 1)}, F2{xmd_field(u, 2), xmd_field(u, 3)}, (int)(lane & 7));
+    if ((lane & 7) == 0) g2_store_aff(out + i * GPBC_G2_BYTES, r);
+}
 GPBC_KERNEL k_g1_map_fields_quad(const uint8_t *__restrict__ u, uint8_t *__restrict__ out, size_t n) {
     const size_t lane = (size_t)blockIdx.x * BLOCK + threadIdx.x, i = lane >> 2;
     if (i >= n) return;
@@ -238,6 +315,7 @@ static int unmarshal_dev(int kind, const void *d_in, size_t elem_bytes, size_t n
     TRY(bind_device());
     hipStream_t st = (hipStream_t)stream;
     if (kind == 0) k_g1_decode<<<grid_for(n), BLOCK, 0, st>>>((const uint8_t *)d_in, (int)elem_bytes, (uint8_t *)d_out, d_ok, n);
+    else if (kind == 1 && n <= WIRE_OCT_MAX) k_g2_decode_oct<<<grid_for(8 * n), BLOCK, 0, st>>>((const uint8_t *)d_in, (int)elem_bytes, (uint8_t *)d_out, d_ok, n);
     else if (kind == 1 && n <= WIRE_QUAD_MAX) k_g2_decode_quad<<<grid_for(4 * n), BLOCK, 0, st>>>((const uint8_t *)d_in, (int)elem_bytes, (uint8_t *)d_out, d_ok, n);
     else if (kind == 1) k_g2_decode<<<grid_for(n), BLOCK, 0, st>>>((const uint8_t *)d_in, (int)elem_bytes, (uint8_t *)d_out, d_ok, n);
     else k_gt_decode<<<grid_for(n), BLOCK, 0, st>>>((const uint8_t *)d_in, (uint8_t *)d_out, d_ok, n);
@@ -318,6 +396,10 @@ static int map_fields_dev(bool g2, const void *d_u, size_t n, void *d_out, void 
     if (!n) return GPBC_OK;
     if (!d_u || !d_out) return fail(GPBC_ERR_INVALID_ARG, "null pointer");
     TRY(bind_device());
+    if (g2 && n <= H2C_OCT_MAX) {
+        k_g2_map_fields_oct<<<grid_for(8 * n), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_u, (uint8_t *)d_out, n);
+        return check_launch("k_g2_map_fields_oct");
+    }
     if (n <= H2C_QUAD_MAX) {
         if (g2) k_g2_map_fields_quad<<<grid_for(4 * n), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_u, (uint8_t *)d_out, n);
         else k_g1_map_fields_quad<<<grid_for(4 * n), BLOCK, 0, (hipStream_t)stream>>>((const uint8_t *)d_u, (uint8_t *)d_out, n);
@@ -376,7 +458,8 @@ static int hash_dev(int what, const void *d_msgs, const uint64_t *d_off, size_t 
         case 0: if (n <= H2C_QUAD_MAX) k_g1_hash_quad<<<grid_for(4 * n), BLOCK, 0, st>>>(m, d_off, msgs_bytes, n, d, o);
                 else k_g1_hash<<<grid_for(n), BLOCK, 0, st>>>(m, d_off, msgs_bytes, n, d, o);
                 break;
-        case 1: if (n <= H2C_QUAD_MAX) k_g2_hash_quad<<<grid_for(4 * n), BLOCK, 0, st>>>(m, d_off, msgs_bytes, n, d, o);
+        case 1: if (n <= H2C_OCT_MAX) k_g2_hash_oct<<<grid_for(8 * n), BLOCK, 0, st>>>(m, d_off, msgs_bytes, n, d, o);
+                else if (n <= H2C_QUAD_MAX) k_g2_hash_quad<<<grid_for(4 * n), BLOCK, 0, st>>>(m, d_off, msgs_bytes, n, d, o);
                 else k_g2_hash<<<grid_for(n), BLOCK, 0, st>>>(m, d_off, msgs_bytes, n, d, o);
                 break;
         case 2: k_hash_to_field<2><<<grid_for(n), BLOCK, 0, st>>>(m, d_off, msgs_bytes, n, d, o); break;

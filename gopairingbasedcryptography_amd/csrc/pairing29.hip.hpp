@@ -191,26 +191,34 @@ GPBC_INLINE void f12_cyclo_sqr_n(F12 &z, int n) {
 GPBC_INLINE void f12_frob_to(F12 &z, const F12 &x, int j) { z = f12_frob(x, j); }
 GPBC_INLINE void f12_inv_to(F12 &z, const F12 &x) { z = f12_inv(x); }
 
-// z = x^u, u = 0x44e992b44a6909f1, x in the cyclotomic subgroup (inverse = conjugate, free): width-4 signed windows
-// over u — 62 squarings + 13 products by x^(+-1,3,5,7) + 4 to build the table, against 27 products for the plain
-// binary method.  A real function: it is used three times by the hard part and its table lives in private memory.
+// z = x^u, u = 0x44e992b44a6909f1, x in the cyclotomic subgroup (inverse = conjugate, free).  Signed digits over the dictionary
+// {x^3, x^15, x^75} (GPBC_U_CHAIN, tools/gen_constants.py: dictionary_digits): x^3 = x^2 x, x^15 = (x^3)^4 x^3, x^75 = (x^15)^4 x^15, then
+// 56 squarings and 10 products — 61 squarings + 13 products in all.  Width-4 windows (rounds 1-3) took 63 + 16, gnark's unsigned chain
+// 62 + 17; a product costs 2.3 cyclotomic squarings, and tools/u_chain_search.py found nothing below 13 products.
+// A real function: it is used three times by the hard part and its table lives in private memory.  (THREE entries, 648 B, on purpose:
+// a table of two — {x^17, x^35}: 62 + 13 — is below the compiler's promote-alloca budget of 512 B, becomes 108 spilled registers, and
+// tab[e] becomes loads of both entries and 54 selects each behind its own wait: k_final_exp's memory waits went from 14 to 28 % of the
+// wave cycles and the kernel was SLOWER with 7 % fewer instructions, profiles/r04_variant_u_chain.txt.)
+GPBC_INLINE int u_chain_entry(int d) { const int a = d < 0 ? -d : d; return (a > 3) + (a > 15); }
 GPBC_NOINLINE void f12_expt_to(F12 &z, const F12 &x) {
-    // wNAF(u, 4), least-significant digit first (tools: sum d_i 2^i == u is asserted in tests/test_device_math_bounds.py)
-    constexpr int8_t D[GPBC_U_WNAF4_LEN] = GPBC_U_WNAF4;
-    static_assert(GPBC_U_WNAF4_LEN == 63, "digit count");
-    F12 tab[4];
-    tab[0] = x;
-    F12 x2 = f12_cyclo_sqr(x);
-    for (int k = 1; k < 4; k++) tab[k] = f12_mul(tab[k - 1], x2);
-    F12 r = tab[(D[62] - 1) / 2];                    // top digit is positive
+    constexpr int8_t D[GPBC_U_CHAIN_LEN] = GPBC_U_CHAIN;    // (sum d_i 2^i == u is asserted in tests/test_device_math_bounds.py)
+    F12 tab[3];
+    F12 r = f12_cyclo_sqr(x);
+    tab[0] = f12_mul(r, x);
+    for (int k = 1; k < 3; k++) {
+        r = tab[k - 1];
+        f12_cyclo_sqr_n(r, 2);
+        tab[k] = f12_mul(r, tab[k - 1]);
+    }
+    r = tab[u_chain_entry(D[GPBC_U_CHAIN_LEN - 1])];         // top digit is positive
     int run = 0;
-    for (int i = 61; i >= 0; i--) {
+    for (int i = GPBC_U_CHAIN_LEN - 2; i >= 0; i--) {
         run++;
         int d = D[i];
         if (d != 0) {
             f12_cyclo_sqr_n(r, run);
             run = 0;
-            F12 t = tab[((d < 0 ? -d : d) - 1) / 2];
+            F12 t = tab[u_chain_entry(d)];
             if (d < 0) t = f12_conj(t);
             r = f12_mul(r, t);
         }

@@ -93,27 +93,31 @@ template <class X, class LineAt> GPBC_INLINE F6 miller_accumulate_multi_34(const
     return h;
 }
 
-// x^u with width-4 signed windows (see f12_expt_to).  The squarings run in the alternating-sign form (f12p_cyclo_sqr_run): after an odd
-// number of them the lane pair holds the CONJUGATE of the running value; conj(r) conj(t) = conj(r t), so the window product takes the
+// x^u over the dictionary {x^3, x^15, x^75} (see f12_expt_to).  The squarings run in the alternating-sign form (f12p_cyclo_sqr_run): after
+// an odd number of them the lane pair holds the CONJUGATE of the running value; conj(r) conj(t) = conj(r t), so a product takes the
 // table entry conjugated exactly when (digit negative) differs from (r conjugated), and one conjugation at the end restores the sign.
 template <class X> GPBC_NOINLINE void f12p_expt_to(const X &x, F6 &z, const F6 &b) {
-    constexpr int8_t D[GPBC_U_WNAF4_LEN] = GPBC_U_WNAF4;
-    // the table entries are kept positive-normalised (one f6_norm each): the window products then run in the subtractive-Karatsuba form
+    constexpr int8_t D[GPBC_U_CHAIN_LEN] = GPBC_U_CHAIN;
+    // the table entries are kept positive-normalised (one f6_norm each): the products then run in the subtractive-Karatsuba form
     // (f12p_mul<true>) — their other operand comes out of a squaring run, which ends in a normalisation
-    F6 tab[4];
-    tab[0] = f6_norm(b);
-    F6 b2 = f12p_cyclo_sqr<true>(x, b);
-    for (int k = 1; k < 4; k++) tab[k] = f6_norm(f12p_mul(x, tab[k - 1], b2));
-    F6 r = tab[(D[GPBC_U_WNAF4_LEN - 1] - 1) / 2];
-    int run = 0;
+    F6 tab[3];
     bool flipped = false;
-    for (int i = GPBC_U_WNAF4_LEN - 2; i >= 0; i--) {
+    F6 r = f12p_cyclo_sqr<true>(x, b);
+    tab[0] = f6_norm(f12p_mul(x, f6_norm(b), r));                       // x^3
+#pragma unroll 1
+    for (int k = 1; k < 3; k++) {                                       // x^15 = (x^3)^4 x^3, x^75 = (x^15)^4 x^15 (even runs: not conjugated)
+        r = f12p_cyclo_sqr_run(x, tab[k - 1], 2, flipped);
+        tab[k] = f6_norm(f12p_mul<true>(x, r, tab[k - 1]));
+    }
+    r = tab[u_chain_entry(D[GPBC_U_CHAIN_LEN - 1])];
+    int run = 0;
+    for (int i = GPBC_U_CHAIN_LEN - 2; i >= 0; i--) {
         run++;
         int d = D[i];
         if (d != 0) {
             r = f12p_cyclo_sqr_run(x, r, run, flipped);
             run = 0;
-            F6 t = tab[((d < 0 ? -d : d) - 1) / 2];
+            F6 t = tab[u_chain_entry(d)];
             if ((d < 0) != flipped) t = f6_norm(f12p_conj(x, t));       // (the negated half normalises to non-negative limbs again)
             r = f12p_mul<true>(x, r, t);
         }

@@ -432,21 +432,25 @@ template <class M, class Fetch> GPBC_INLINE void wide_miller_accumulate(M &m, in
 
 // ---- final exponentiation (operation order of final_exp29 / final_exp_pair)
 template <class M> GPBC_INLINE void wide_cyclo_sqr_n(M &m, int v, int n) { for (int i = 0; i < n; i++) wide_cyclo_sqr(m, v, v); }
-// z = x^u, width-4 signed windows; tab = four consecutive values, tmp = one value
+// z = x^u over the dictionary {x^3, x^15, x^75} (f12_expt_to); tab = three consecutive values, tmp = one value
 template <class M> GPBC_INLINE void wide_expt(M &m, int z, int x, int tab, int tmp) {
-    constexpr int8_t D[GPBC_U_WNAF4_LEN] = GPBC_U_WNAF4;
-    wide_copy(m, tab, x);
+    constexpr int8_t D[GPBC_U_CHAIN_LEN] = GPBC_U_CHAIN;
     wide_cyclo_sqr(m, tmp, x);
-    for (int k = 1; k < 4; k++) wide_mul(m, tab + 6 * k, tab + 6 * (k - 1), tmp);
-    wide_copy(m, z, tab + 6 * ((D[GPBC_U_WNAF4_LEN - 1] - 1) / 2));
+    wide_mul(m, tab, tmp, x);                                  // x^3
+    for (int k = 1; k < 3; k++) {                              // x^15, x^75
+        wide_cyclo_sqr(m, tmp, tab + 6 * (k - 1));
+        wide_cyclo_sqr(m, tmp, tmp);
+        wide_mul(m, tab + 6 * k, tmp, tab + 6 * (k - 1));
+    }
+    wide_copy(m, z, tab + 6 * u_chain_entry(D[GPBC_U_CHAIN_LEN - 1]));
     int run = 0;
-    for (int i = GPBC_U_WNAF4_LEN - 2; i >= 0; i--) {
+    for (int i = GPBC_U_CHAIN_LEN - 2; i >= 0; i--) {
         run++;
         const int d = D[i];
         if (d != 0) {
             wide_cyclo_sqr_n(m, z, run);
             run = 0;
-            const int e = tab + 6 * (((d < 0 ? -d : d) - 1) / 2);
+            const int e = tab + 6 * u_chain_entry(d);
             if (d < 0) { wide_conj(m, tmp, e); wide_mul(m, z, z, tmp); }
             else wide_mul(m, z, z, e);
         }

@@ -146,6 +146,10 @@ def test_wnaf_digits_of_u():
     text = open(os.path.join(ROOT, "gopairingbasedcryptography_amd", "csrc", "bn254_constants.hip.hpp")).read()
     digits = [int(x) for x in re.search(r"#define GPBC_U_WNAF4 \{([^}]*)\}", text).group(1).split(",")]
     assert sum(d << i for i, d in enumerate(digits)) == o.U and all(d == 0 or (d % 2 and abs(d) < 8) for d in digits)
+    # the device chain: digits over the dictionary {x^3, x^15, x^75}
+    chain = [int(x) for x in re.search(r"#define GPBC_U_CHAIN \{([^}]*)\}", text).group(1).split(",")]
+    assert sum(d << i for i, d in enumerate(chain)) == o.U and all(abs(d) in (0, 3, 15, 75) for d in chain) and chain[-1] > 0
+    assert len(chain) == int(re.search(r"#define GPBC_U_CHAIN_LEN (\d+)", text).group(1))
 
 
 def test_glv_split_identity(hc):

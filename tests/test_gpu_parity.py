@@ -373,7 +373,7 @@ def test_point_sums(eng, oracle, synth):
 
 
 def test_scalar_mul_one_point_per_quad_and_per_lane_agree(eng, oracle):
-    """Calls of up to 16 384 points run one point per QUAD of lanes (csrc/curve29_quad.hip.hpp: the loop's doublings and additions three
+    """Calls of up to 2 048 G2 points run one point per OCTET of lanes, calls of up to 16 384 points one point per QUAD of lanes (csrc/curve29_quad.hip.hpp: the loop's doublings and additions three
     products wide), larger ones one point per lane: the same random points and 256-bit scalars through both, and against the oracle on a
     sample; infinity, zero and tiny scalars, and a shared base included."""
     g1, g2 = eng.generators()
@@ -389,6 +389,9 @@ def test_scalar_mul_one_point_per_quad_and_per_lane_agree(eng, oracle):
         lane = mul(base, k2.reshape(-1)).reshape(n, w)              # one point per lane
         quad = mul(base[:16384], k2[:16384].reshape(-1)).reshape(16384, w)
         assert (quad == lane[:16384]).all()
+        # calls of up to 2 048 points: G2 runs one point per OCTET of lanes (csrc/curve29_oct.hip.hpp: half Fp2 products on lane pairs)
+        for lo, hi in ((0, 2048), (0, 1), (5, 6), (100, 107), (3000, 5047)):
+            assert (mul(base[lo:hi], k2[lo:hi].reshape(-1)).reshape(hi - lo, w) == lane[lo:hi]).all(), (w, lo, hi)
         assert (lane[pick] == np.asarray(omul(base[pick], k2[pick].reshape(-1), threads=8)).reshape(-1, w)).all()
         if w == 128:                                                # G2 decoding: the subgroup test per quad (<= 16 384) and per lane
             enc = np.asarray(eng.g2_marshal(lane, compressed=True)).reshape(n, 64)
@@ -399,6 +402,11 @@ def test_scalar_mul_one_point_per_quad_and_per_lane_agree(eng, oracle):
             _, okb_l = eng.g2_unmarshal(bad.reshape(-1), elem_bytes=64)
             _, okb_q = eng.g2_unmarshal(bad[:16384].reshape(-1), elem_bytes=64)
             assert not okb_l[9] and not okb_l[16384] and not okb_q[9] and okb_l.sum() == n - 2 and okb_q.sum() == 16383
+            back_o, ok_o = eng.g2_unmarshal(enc[:2048].reshape(-1), elem_bytes=64)                 # ... and per octet (<= 2 048)
+            _, okb_o = eng.g2_unmarshal(bad[:2048].reshape(-1), elem_bytes=64)
+            assert ok_o.all() and (back_o == lane[:2048]).all() and not okb_o[9] and okb_o.sum() == 2047
+            m2, ok2 = eng.g2_unmarshal(np.asarray(eng.g2_marshal(lane[:2048], compressed=False)).reshape(-1), elem_bytes=128)   # raw form
+            assert ok2.all() and (m2 == lane[:2048]).all()
         shared = mul(base[7], k2[:300].reshape(-1)).reshape(300, w)  # one base, 300 scalars: the quad kernel's shared-base form
         assert (shared == np.asarray(omul(np.tile(base[7], (300, 1)), k2[:300].reshape(-1), threads=8)).reshape(-1, w)).all()
 

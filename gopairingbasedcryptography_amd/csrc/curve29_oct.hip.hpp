@@ -3,9 +3,11 @@
 // one 486-MAD leaf), and a lone wave issues one MAD per ~9 cycles whatever else it does, so the halves go to the two lanes of a PAIR
 // and an octet holds four product slots.  A level then costs half the multiplier time of the quad form; the two halves meet again
 // through one DPP pair swap and a product reaches the other lanes of the octet through ds_bpermute.  Same values as jac_dbl /
-// jac_add_mixed / gls_table29 (the half products are the components of f2_mul's result, limb for limb).  Used for single
-// ScalarMultiplication calls in G2 (signature/bls01_signature/bls_signature.go:63: every BLS Sign) — calls of a few points, where the
-// depth of the chain is all that counts.  All eight lanes of an octet must be active together (one point: they share every branch).
+// jac_add_mixed / gls_table29 (the half products are the components of f2_mul's result, limb for limb).  Used for calls of up to 2 048
+// elements, where the depth of the chain is all that counts: ScalarMultiplication in G2 (signature/bls01_signature/bls_signature.go:63:
+// every BLS Sign; gpbc_curve.hip: k_g2_scalar_mul_oct), the [x]P chains of HashToG2's cofactor clearing (hash/hash_to.go:271-277) and of
+// G2 Unmarshal's subgroup test (serialization/serialization_curve.go:23-27; gpbc_wire.hip: k_g2_hash_oct, k_g2_map_fields_oct,
+// k_g2_decode_oct).  All eight lanes of an octet must be active together (one point: they share every branch).
 #ifndef GPBC_CURVE29_OCT_HIP_HPP
 #define GPBC_CURVE29_OCT_HIP_HPP
 #include "curve29_quad.hip.hpp"

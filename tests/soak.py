@@ -2,7 +2,7 @@
 """Randomised soak of the GPU engine against the C restatement (oracle/): many more inputs than the test-suite uses, to
 reach rare paths (exact zero tests, exceptional additions, large table indices).  Test infrastructure (it imports the oracle, so it
 lives under tests/; not collected by pytest) — run on a GPU box:
-    python tests/soak.py [n]        (default n = 65536)
+    python tests/soak.py [n [seed]]        (default n = 65536, seed 20261004)
 """
 import os
 import sys
@@ -20,7 +20,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 threads = min(len(os.sched_getaffinity(0)), 16)
 oracle_lib.build()
 bn254.init(0)
-rng = np.random.default_rng(20261004)
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 20261004
+rng = np.random.default_rng(seed)
 
 
 def scal(m, full=False):
@@ -134,4 +135,4 @@ assert (H1 == hash_to.hash_to_g1_via_host_fields(msgs, b"soak")).all() and (H2 =
 back, ok = bn254.g2_unmarshal(bn254.g2_marshal(H2))
 assert ok.all() and (back == H2).all(), "hashed G2 points are in the group"
 print("hash to field / curve ok  (%d messages, %.1f s)" % (len(msgs), time.time() - t0), flush=True)
-print("soak OK")
+print("soak OK  (n = %d, seed = %d)" % (n, seed))

@@ -34,3 +34,11 @@ def oracle():
     import oracle_lib
     oracle_lib.build()
     return oracle_lib
+
+
+def eip197_pairs(words):
+    """EIP-197 words (hex, big-endian) -> ([(x, y)], [((x.re, x.im), (y.re, y.im))]) as Python integers (tests/golden/eip197_pairing.json)"""
+    w = [int(h, 16) for h in words]
+    ps = [(w[6 * k], w[6 * k + 1]) for k in range(len(w) // 6)]
+    qs = [((w[6 * k + 3], w[6 * k + 2]), (w[6 * k + 5], w[6 * k + 4])) for k in range(len(w) // 6)]
+    return ps, qs

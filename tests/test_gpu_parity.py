@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import bn254_py as o
-from conftest import cat, hx, load_golden
+from conftest import cat, eip197_pairs, hx, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -77,6 +77,26 @@ def test_pair_single_call_semantics(eng):
         eng.pair(np.concatenate([g1, g1]), g2)
     with pytest.raises(ValueError, match="invalid inputs sizes"):
         eng.pair(np.zeros(0, dtype=np.uint8), np.zeros(0, dtype=np.uint8))
+
+
+def test_published_pairing_check_vector(eng):
+    """The EIP-197 known answer (tests/golden/eip197_pairing.json; an external vector, see tests/test_oracle.py) through the engine:
+    PairingCheck accepts it in the latency form and through the throughput kernels, and rejects it with another second point."""
+    from gopairingbasedcryptography_amd import _lib
+    for c in load_golden("eip197_pairing.json")["cases"]:
+        ps, qs = eip197_pairs(c["words"])
+        P = np.frombuffer(b"".join(o.g1_to_bytes(p) for p in ps), dtype=np.uint8)
+        Q = np.frombuffer(b"".join(o.g2_to_bytes(q) for q in qs), dtype=np.uint8)
+        Q2 = np.frombuffer(o.g2_to_bytes(qs[0]) + o.g2_to_bytes(o.g2_mul(o.G2_GEN, 2)), dtype=np.uint8)
+        one = np.frombuffer(o.gt_to_bytes(o.F12_ONE), dtype=np.uint8)
+        for limit in (2048, 0):
+            _lib.check(_lib.load().gpbc_set_latency_path(limit))
+            try:
+                assert bool(eng.pairing_check(P, Q)) == c["expected"]
+                assert not eng.pairing_check(P, Q2)
+                assert (np.asarray(eng.pair(P, Q)).reshape(-1) == one).all() == c["expected"]
+            finally:
+                _lib.load().gpbc_set_latency_path(2048)
 
 
 def test_multi_pair_golden(eng):

@@ -5,7 +5,7 @@ determinism zss04_signature_test.go:26-38, round trips)."""
 import numpy as np
 
 import bn254_py as o
-from conftest import cat, hx, load_golden
+from conftest import cat, eip197_pairs, hx, load_golden
 
 
 def test_python_oracle_self_check():
@@ -18,6 +18,27 @@ def test_known_public_constants():
     assert g["two_g1_decimal"] == [
         "1368015179489954701390400359078579693043519447331113978918064868415326638035",
         "9918110051302171585080402603319702774565515993150576347155970296011118125764"]
+
+
+def test_published_pairing_check_vector(oracle):
+    """An EXTERNAL known answer (tests/golden/eip197_pairing.json: a vector of the Ethereum alt_bn128 pairing precompile, EIP-197): two
+    pairs of points nobody here chose whose pairing product is one.  Pins, for both restatements, the curve and twist equations, the
+    Fp2 / G2 coordinate conventions, the standard G2 generator (it is the vector's second Q) and that the pairing is the bilinear,
+    non-degenerate map the precompile computes — not gnark's GT bytes (the check is blind to the exponent's cofactor and to byte order)."""
+    for c in load_golden("eip197_pairing.json")["cases"]:
+        ps, qs = eip197_pairs(c["words"])
+        assert all(o.g1_is_on_curve(p) for p in ps) and all(o.g2_is_on_curve(q) and o.g2_in_subgroup(q) for q in qs), "vector mistyped"
+        assert qs[1] == o.G2_GEN
+        assert (o.pair(ps, qs) == o.F12_ONE) == c["expected"]
+        P = np.frombuffer(b"".join(o.g1_to_bytes(p) for p in ps), dtype=np.uint8)
+        Q = np.frombuffer(b"".join(o.g2_to_bytes(q) for q in qs), dtype=np.uint8)
+        one = np.frombuffer(o.gt_to_bytes(o.F12_ONE), dtype=np.uint8)
+        off = np.array([0, len(ps)], dtype=np.uint64)
+        assert (np.asarray(oracle.multi_pair(P, Q, off, threads=2)).reshape(-1) == one).all() == c["expected"]
+        # any other second point breaks it
+        Q2 = np.frombuffer(o.g2_to_bytes(qs[0]) + o.g2_to_bytes(o.g2_mul(o.G2_GEN, 2)), dtype=np.uint8)
+        assert not (np.asarray(oracle.multi_pair(P, Q2, off, threads=2)).reshape(-1) == one).all()
+        assert o.pair(ps, [qs[0], o.g2_mul(o.G2_GEN, 2)]) != o.F12_ONE
 
 
 def test_pairing_golden(oracle):

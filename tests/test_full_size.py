@@ -183,3 +183,36 @@ def test_pipelined_host_entries_match_the_device_path(eng, dev):
     assert (eng.pair_batch(Ph, Qh) == gt.cpu().numpy()).all()
     assert (eng.g1_scalar_mul(Ph, kh) == eng.g1_scalar_mul(P, ks).cpu().numpy()).all()
     assert (eng.g2_scalar_mul(Qh, kh) == eng.g2_scalar_mul(Q, ks).cpu().numpy()).all()
+
+
+def test_beyond_the_baseline_size(eng, oracle, dev):
+    """Four times BASELINE's batch and ragged: 2^22 + 17 pairs in ONE device call (seventeen 262 144-pair workspace chunks, the last of
+    17 pairs) and as many scalar multiplications in each group; a window that straddles the 2^22 boundary and windows elsewhere must be
+    the bytes of separate small calls, the tail and a few interior rows the oracle's.  (Sizes are size_t throughout the ABI; this is the
+    largest batch the suite runs — 2.4 GB of points and results in HBM.)"""
+    import torch
+    import bench_workloads as w
+    n = (1 << 22) + 17
+    g1, g2 = eng.generators()
+    d = lambda a: torch.from_numpy(np.array(a, dtype=np.uint8, copy=True)).to(dev)
+    rng = np.random.default_rng(4222)
+    kP, kQ = rng.integers(0, 256, size=(n, 32), dtype=np.uint8), rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    kP[:, 31] &= 0x1F; kQ[:, 31] &= 0x1F                                          # below 2^253 < r
+    kP, kQ = d(kP), d(kQ)
+    P, Q = eng.g1_scalar_mul(d(g1), kP), eng.g2_scalar_mul(d(g2), kQ)             # one shared base: the transient fixed-base table
+    assert P.shape[0] == n and Q.shape[0] == n
+    gt = eng.pair_batch(P, Q)
+    R1, R2 = eng.g1_scalar_mul(P, kQ), eng.g2_scalar_mul(Q, kP)                   # one base per scalar: the variable-base kernels
+    torch.cuda.synchronize()
+    for lo, hi in ((0, 300), (262144 - 100, 262144 + 100), ((1 << 22) - 200, n), (3 * (1 << 20) + 12345, 3 * (1 << 20) + 12345 + 2500)):
+        assert torch.equal(eng.pair_batch(P[lo:hi].contiguous(), Q[lo:hi].contiguous()), gt[lo:hi]), (lo, hi)
+        assert torch.equal(eng.g1_scalar_mul(P[lo:hi].contiguous(), kQ[lo:hi].contiguous()), R1[lo:hi]), (lo, hi)
+        assert torch.equal(eng.g2_scalar_mul(Q[lo:hi].contiguous(), kP[lo:hi].contiguous()), R2[lo:hi]), (lo, hi)
+    idx = np.array([0, 1, (1 << 21) + 3, (1 << 22) - 1, 1 << 22, n - 2, n - 1])
+    Ps, Qs, k1, k2 = P[idx].cpu().numpy(), Q[idx].cpu().numpy(), kQ[idx].cpu().numpy(), kP[idx].cpu().numpy()
+    assert (gt[idx].cpu().numpy() == oracle.pair_batch(Ps, Qs, threads=8)).all()
+    assert (R1[idx].cpu().numpy() == oracle.g1_scalar_mul(Ps, k1.reshape(-1), threads=8)).all()
+    assert (R2[idx].cpu().numpy() == oracle.g2_scalar_mul(Qs, k2.reshape(-1), threads=8)).all()
+    one = torch.from_numpy(np.frombuffer(o.gt_to_bytes(o.F12_ONE), dtype=np.uint8).copy()).to(dev)
+    assert not bool((gt == one).all(dim=1).any())                                 # no output is one, none is zero
+    assert bool(gt.any(dim=1).all())

@@ -18,14 +18,24 @@ struct LineE { F2 r0, r1, r2; };  // l = r0*yP + r1*xP*w + r2*w^3
 
 GPBC_INLINE int ate_naf_digit(int i) { constexpr int8_t D[BN254_ATE_NAF_LEN] = BN254_ATE_NAF; return D[i]; }
 
+// (9 - i)(a0 + a1 i) = (9 a0 + a1) + (9 a1 - a0) i: the curve coefficient of the isomorphic twist (below), value-reduced in front of
+// its one normalisation (|value| < 0.51 p, limbs 0..7 non-negative like a product's: the sums B + 3E of the doubling sit one unit
+// below 2^31 and have no room for signed limbs) — what the product by b' returned, without the product.  Input N-class.
+GPBC_INLINE F2 f2_mul_9mi_n(const F2 &x) {
+    return F2{fe_reduce_arith_norm(fe_add(fe_add(fe_mul8_norm(x.a0), x.a0), x.a1)), fe_reduce_arith_norm(fe_sub(fe_add(fe_mul8_norm(x.a1), x.a1), x.a0))};
+}
 // Tangent line at T and T <- 2T (Costello-Lange-Naehrig, ePrint 2013/722 §4.3, a = 0 twist). T in/out N-class.
-GPBC_INLINE void g2_double_step(G2P &t, LineE &l) {
+// ISO: the walk runs on the isomorphic twist y^2 = x^3 + (9 - i) (miller_lines), whose coefficient costs additions, not an F2 product.
+template <bool ISO = false> GPBC_INLINE void g2_double_step(G2P &t, LineE &l) {
     F2 A = f2_halve(f2_mul(t.x, t.y));
     F2 B = f2_sqr(t.y);
     F2 C = f2_sqr(t.z);
-    F2 E = f2_mul(f2_norm(f2_add(f2_dbl(C), C)), b_twist29());
+    F2 C3 = f2_norm(f2_add(f2_dbl(C), C));
+    F2 E = ISO ? f2_mul_9mi_n(C3) : f2_mul(C3, b_twist29());
     F2 F = f2_add(f2_dbl(E), E);
-    F2 G = f2_halve(f2_norm(f2_add(B, F)));
+    // G = (B + 3E) / 2.  A product's limbs are masked (below 2^29) and B + 3E fits int32 by four units; E out of fe_norm may sit a carry
+    // above 2^29, so the ISO form takes G = E + (B + E) / 2 (f2_sqr_n normalises its operand either way)
+    F2 G = ISO ? f2_add(E, f2_halve(f2_norm(f2_add(B, E)))) : f2_halve(f2_norm(f2_add(B, F)));
     F2 H = f2_sub(f2_sqr_n(f2_add(t.y, t.z)), f2_add(B, C));
     F2 J = f2_sqr(t.x);
     F2 EE = f2_sqr(E);
@@ -72,12 +82,23 @@ GPBC_INLINE LineS line_scale(const LineE &l, const G1A &p) { return LineS{f2_mul
 // Phase A of the Miller loop — the G2 arithmetic.  The sequence of lines depends only on (P, Q), never on the
 // accumulator f, so it runs on its own (own kernel, own register budget) and hands the 88 lines to phase B.
 // sink(LineS) is called once per line, in evaluation order.  Caller has checked neither point is infinity.
-template <class Sink> GPBC_INLINE void miller_lines(const G1A &p, const G2A &q, Sink &&sink) {
+// The walk runs on an ISOMORPHIC curve pair: (x, y) -> (t^2 x, t^3 y), t in Fp with t^6 = 82/3, takes E: y^2 = x^3 + 3 and the twist
+// E': y^2 = x^3 + 3/(9+i) to y^2 = x^3 + 82 and y^2 = x^3 + (9 - i), where the doubling's product by the twist coefficient is a few
+// additions (f2_mul_9mi_n) instead of one of its four F2 products.  P and Q are mapped once (six Fp products); the Frobenius
+// endpoints commute with the map (t is in Fp).  Every line then equals gnark's times a power of t that depends on the step alone —
+// an Fp factor, which the final exponentiation removes — and the LAST line carries the constant t^-N (F29_ISO_KFIX, derived in
+// tools/gen_constants.py iso_twist_constants) that cancels their product, so that the Miller value itself, not only the pairing, is
+// the one the other forms and gnark's MillerLoop give.
+template <class Sink> GPBC_INLINE void miller_lines(const G1A &p0, const G2A &q0, Sink &&sink) {
+    constexpr int32_t T2[NL] = F29_ISO_T2, T3[NL] = F29_ISO_T3, KF[NL] = F29_ISO_KFIX;
+    const Fe t2 = fe_const(T2), t3 = fe_const(T3);
+    const G1A p{fe_mul(p0.x, t2), fe_mul(p0.y, t3)};
+    const G2A q{f2_mul_fe(q0.x, t2), f2_mul_fe(q0.y, t3)};
     G2P t{q.x, q.y, f2_one()};
     const F2 ny = f2_neg(q.y);
     LineE l;
     for (int i = BN254_ATE_NAF_LEN - 2; i >= 0; i--) {
-        g2_double_step(t, l);
+        g2_double_step<true>(t, l);
         sink(line_scale(l, p));
         int d = ate_naf_digit(i);
         if (d != 0) {
@@ -90,7 +111,8 @@ template <class Sink> GPBC_INLINE void miller_lines(const G1A &p, const G2A &q, 
     g2_add_step(t, l, q1);
     sink(line_scale(l, p));
     g2_line_step(t, l, q2);
-    sink(line_scale(l, p));
+    const Fe k = fe_const(KF);
+    sink(LineS{f2_mul_fe(l.r0, fe_mul(p.y, k)), f2_mul_fe(l.r1, fe_mul(p.x, k)), f2_mul_fe(l.r2, k)});
 }
 
 // The same walk WITHOUT the evaluation point: the raw coefficients (r0, r1, r2) of the 88 lines depend on Q alone, so a

@@ -128,3 +128,61 @@ def test_fp_mul_audit_counts(oracle):
     c = oracle.fp_mul_counts()
     assert 5000 < c["miller_loop"] < 15000 and 4000 < c["final_exp"] < 12000
     assert 1500 < c["g1_scalar_mul"] < 6000 and 4000 < c["g2_scalar_mul"] < 14000
+
+
+def test_isomorphic_twist_line_phase_constants():
+    """The line phase of the throughput Miller loop (csrc/pairing29.hip.hpp miller_lines) walks G2 on y^2 = x^3 + (9 - i) with P and Q
+    mapped by (x, y) -> (t^2 x, t^3 y) and multiplies its LAST line by a constant (tools/gen_constants.py iso_twist_constants).  Here the
+    same projective NAF walk in big integers, once on gnark's twist and once on the isomorphic one: the two Miller VALUES must be equal
+    as elements of Fp12 (not only their final exponentiations), which is what keeps every form of the engine comparable value by value."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import gen_constants as gc
+    t2, t3, kfix = gc.iso_twist_constants()
+    assert pow(t3, 2, o.P) == pow(t2, 3, o.P) and o.f2_scal(o.B_G2, pow(t2, 3, o.P)) == (9, o.P - 1)      # b' t^6 = 9 - i
+    digits = gc.naf(o.ATE_LOOP)
+    half = pow(2, -1, o.P)
+
+    def walk(p, q, b, last):
+        """gnark's projective steps (A = XY/2 ... Z3 = BH; chord through an affine point), lines l = r0 yP + r1 xP w + r2 w^3"""
+        X, Y, Z = q[0], q[1], o.F2_ONE
+        f = None
+
+        def line(r0, r1, r2, k=1):
+            c = [o.F2_ZERO] * 6
+            c[0], c[1], c[3] = o.f2_scal(r0, p[1] * k % o.P), o.f2_scal(r1, p[0] * k % o.P), o.f2_scal(r2, k)
+            return o.f12_from_w_coeffs(c)
+
+        def dbl():
+            nonlocal X, Y, Z
+            A = o.f2_scal(o.f2_mul(X, Y), half); B = o.f2_sqr(Y); C = o.f2_sqr(Z)
+            E = o.f2_mul(o.f2_scal(C, 3), b); F = o.f2_scal(E, 3); G = o.f2_scal(o.f2_add(B, F), half)
+            H = o.f2_sub(o.f2_sqr(o.f2_add(Y, Z)), o.f2_add(B, C)); J = o.f2_sqr(X); EE = o.f2_sqr(E)
+            X, Y, Z = o.f2_mul(A, o.f2_sub(B, F)), o.f2_sub(o.f2_sqr(G), o.f2_scal(EE, 3)), o.f2_mul(B, H)
+            return o.f2_neg(H), o.f2_scal(J, 3), o.f2_sub(E, B)
+
+        def add(a, update=True):
+            nonlocal X, Y, Z
+            O = o.f2_sub(Y, o.f2_mul(a[1], Z)); L = o.f2_sub(X, o.f2_mul(a[0], Z))
+            r = (L, o.f2_neg(O), o.f2_sub(o.f2_mul(a[0], O), o.f2_mul(L, a[1])))
+            if update:
+                C = o.f2_sqr(O); D = o.f2_sqr(L); E = o.f2_mul(L, D); F = o.f2_mul(Z, C); G = o.f2_mul(X, D)
+                H = o.f2_sub(o.f2_add(E, F), o.f2_scal(G, 2))
+                X, Y, Z = o.f2_mul(L, H), o.f2_sub(o.f2_mul(o.f2_sub(G, H), O), o.f2_mul(Y, E)), o.f2_mul(E, Z)
+            return r
+
+        for i in range(len(digits) - 2, -1, -1):
+            l = line(*dbl())
+            f = l if f is None else o.f12_mul(o.f12_sqr(f), l)
+            if digits[i]:
+                f = o.f12_mul(f, line(*add(q if digits[i] > 0 else o.g2_neg(q))))
+        f = o.f12_mul(f, line(*add(o.g2_frobenius(q))))
+        return o.f12_mul(f, line(*add(o.g2_neg(o.g2_frobenius2(q)), update=False), k=last))
+
+    for i in range(2):
+        p, q = o.g1_mul(o.G1_GEN, o.bench_scalar("isoP", i)), o.g2_mul(o.G2_GEN, o.bench_scalar("isoQ", i))
+        plain = walk(p, q, o.B_G2, 1)
+        mapped = walk((p[0] * t2 % o.P, p[1] * t3 % o.P), (o.f2_scal(q[0], t2), o.f2_scal(q[1], t3)), (9, o.P - 1), kfix)
+        assert mapped == plain
+        assert o.final_exp(plain) == o.pair([p], [q])             # and the walk itself is the pairing's Miller function
